@@ -1,0 +1,123 @@
+/* libvcengine -- C ABI of the MI355X-native VerseCrafter denoising engine.
+ *
+ * The drop-in boundary for the hot path of ztitomir/VerseCrafter: one denoise step =
+ * VerseCrafterWanTransformer3DModel.forward (Wan2.1 DiT + GeoAdapter), as driven by
+ * WanVerseCrafterPipeline.__call__'s loop.  The reference is pure Python and has no FFI of its own;
+ * each entry point below cites the reference interface it stands in for (paths relative to the
+ * reference root; WT.py = versecrafter/models/wan_transformer3d.py,
+ * VC.py = versecrafter/models/wan_transformer3d_versecrafter.py,
+ * PIPE.py = versecrafter/pipeline/pipeline_wan_versecrafter.py).  The ctypes binding a maintainer would add
+ * is shown in INTEGRATION.md and shipped as versecrafter_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C types only; tensors are raw DEVICE pointers (bf16 unless stated), row-major, caller-owned.
+ *   - the library borrows weight pointers until vc_destroy and owns only its workspace.
+ *   - every call returns 0 (VC_OK) or a negative VC_E_* code; vc_last_error gives the message.
+ *   - kernels are enqueued on the given hipStream_t (void*; NULL = default stream); no host sync,
+ *     no allocation inside vc_forward.  Handles are not thread-safe.
+ *   - gfx950 only.  There is no CPU fallback: without a HIP device every compute entry fails with VC_E_HIP.
+ */
+#ifndef VCENGINE_H
+#define VCENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_E_INVALID (-1)     /* bad argument / shape                               */
+#define VC_E_HIP (-2)         /* HIP runtime error (message has hipGetErrorString)   */
+#define VC_E_STATE (-3)       /* call order violated (e.g. forward before prepare)   */
+#define VC_E_NOMEM (-4)
+#define VC_E_UNSUPPORTED (-5) /* shape outside what the kernels implement            */
+
+#define VC_ABI_VERSION 1
+#define VC_MAX_GEOADA_LAYERS 64
+
+typedef struct vc_engine vc_engine;
+
+/* Hyper-parameters of VerseCrafterWanTransformer3DModel.__init__ (VC.py:153-170). */
+typedef struct vc_config {
+    int32_t dim, ffn_dim, num_heads, num_layers;
+    int32_t in_dim, out_dim, geoada_in_dim;
+    int32_t text_dim, text_len, freq_dim;
+    float eps;
+    int32_t num_geoada_layers;                       /* 0 -> range(0, num_layers, 2)  (VC.py:175) */
+    int32_t geoada_layers[VC_MAX_GEOADA_LAYERS];
+} vc_config;
+
+/* vc_forward flags: the TeaCache branches of VC.py:384-411 */
+#define VC_FWD_RUN_MAIN_BLOCKS 1u   /* run self.blocks (should_calc)                         */
+#define VC_FWD_STORE_RESIDUAL 2u    /* keep x_out - x_in  (previous_residual_cond)           */
+#define VC_FWD_USE_RESIDUAL 4u      /* x = x + previous_residual instead of the main blocks */
+
+int vc_abi_version(void);
+const char* vc_last_error(const vc_engine* h);     /* h may be NULL: last error of a failed vc_create */
+
+/* VerseCrafterWanTransformer3DModel.__init__ (VC.py:151-201). */
+int vc_create(const vc_config* cfg, vc_engine** out);
+void vc_destroy(vc_engine* h);
+
+/* load_state_dict (WT.py:1302-1311): key = reference state-dict name, shape = its shape.  dtype: 0 = bf16. */
+int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype, int ndim, const int64_t* shape);
+/* number of state-dict keys still unset (0 = ready) */
+int vc_missing_weights(const vc_engine* h);
+
+/* self.freqs (WT.py:783-795; enable_riflex WT.py:873-888): HOST complex128 table [rows][cols] as (re, im) doubles */
+int vc_set_rope_table(vc_engine* h, const double* cis, int rows, int cols);
+
+/* enable_multi_gpus_inference (WT.py:901-921) + the sequence chunking of VC.py:269-270, 366-367.
+ * The self-attention exchange (third-party usp_attn_forward, bound at WT.py:907-921) is delegated to the host
+ * through two callbacks so that the collective itself stays in torch.distributed / RCCL:
+ *   all_to_all(ctx, send, recv, bytes_per_peer, stream): peer r's slice is send[r*bytes_per_peer ...]
+ *   all_gather(ctx, send, recv, bytes, stream)                                                          */
+typedef int (*vc_all_to_all_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+typedef int (*vc_all_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes, void* stream);
+int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_gather_fn ag, void* ctx);
+
+/* Step-invariant part of forward, hoisted (once per video): geoada_patch_embedding (VC.py:262-267),
+ * text_embedding (VC.py:358-363) and every block's cross-attention k/v (WT.py:421-422).
+ *   geoada_context [B, geoada_in_dim, T, H, W]; text[i] = [text_lens[i], text_dim]; seq_len as PIPE.py:861-865. */
+int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const* text, const int32_t* text_lens,
+                     int B, int T, int H, int W, int seq_len, void* stream);
+
+/* VerseCrafterWanTransformer3DModel.forward (VC.py:295-442) for the prepared video.
+ *   x [B, in_dim, T, H, W] bf16, t [B] fp32 (device), out [B, out_dim, T, H, W] bf16.                        */
+int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geoada_context_scale,
+               uint32_t flags, void* stream);
+
+/* time-embedding only: e0 [B, 6, dim] fp32 (device) for the TeaCache gate (WT.py:205-245), VC.py:347-354 */
+int vc_time_embedding(vc_engine* h, const float* t, int B, float* e0_out, void* stream);
+
+/* bytes of library-owned device workspace currently allocated */
+int64_t vc_workspace_bytes(const vc_engine* h);
+
+/* ---- per-kernel entry points (parity tests call the hot kernels in isolation) ------------------------ */
+
+/* nn.Linear (+ fused epilogue): C[M,N] = epi(A[M,K] . W[N,K]^T + bias).  epilogue: 0 bias, 1 bias+gelu(tanh),
+ * 2 resid + y, 3 resid + y*gate[b] (+ hint*hint_scale).  rows_per_batch selects gate row b = m / rows_per_batch. */
+int vc_op_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias,
+                    int M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate,
+                    int64_t gate_bstride, int rows_per_batch, const void* hint, int64_t ldh, float hint_scale,
+                    int tile /*0 auto, 1: 128x128, 2: 256x256*/, void* stream);
+
+/* attention() of videox_fun as called at WT.py:394-399 / 425-430.  q,k,v,out: [B, L, H, 128] with element
+ * strides (batch, token, head); keys >= k_len masked (0 = none). */
+int vc_op_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                    const int64_t* o_strides, int k_len, float scale, void* stream);
+
+/* WanLayerNorm + modulate (mode 0: y = LN(x)*(1+p0[b])+p1[b]) or affine (mode 1: y = LN(x)*p0+p1). */
+int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
+                    const void* p0, const void* p1, int64_t p_bstride, void* stream);
+
+/* WanRMSNorm (+ rope_apply when table != NULL), in place.  table: DEVICE float2 [1024][64] (cos, sin);
+ * grid = {F, H, W, token_offset, rows_per_batch}. */
+int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps, const void* table,
+                       const int32_t* grid5, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCENGINE_H */

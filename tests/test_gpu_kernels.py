@@ -1,0 +1,204 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (libvcengine.so) and checked against the
+CPU oracle (oracle/wan_oracle.py) on the same seeded inputs.  Tolerances: outputs are bf16, so a result
+may differ from the fp32 oracle by bf16 rounding of the output (2^-8 relative) plus the bf16 rounding the
+reference itself applies at intermediate points; each test states its bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from versecrafter_amd import ops as vops
+    from versecrafter_amd import _lib
+    _lib.load()
+    return vops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rs_randn(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def assert_bf16_close(got, want, ulps=2.0, atol=1e-3, what=""):
+    """|got - want| <= ulps * 2^-8 * |want| + atol elementwise (want fp32 oracle, got bf16 kernel)."""
+    got = got.float().cpu()
+    want = want.float()
+    err = (got - want).abs()
+    bound = ulps * BF16_EPS * want.abs() + atol
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} outside bound; max err {err.max():.4g} " \
+                          f"at want={want.flatten()[err.argmax()]:.4g}"
+
+
+def rel_l2(got, want):
+    got, want = got.float().cpu(), want.float()
+    return ((got - want).norm() / want.norm()).item()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 768, 1024), (37, 64, 64), (513, 256, 128)])
+def test_gemm_bias(ops, tile, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
+    want = O.linear(a.float(), w.float(), b.float())
+    got = ops.gemm(dev(a), dev(w), dev(b), tile=tile)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, want, ulps=1.01, atol=2e-3, what="gemm bias")
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric W catches a transposed / row-col swapped C write."""
+    K = 128
+    a = bf(torch.eye(K))
+    w = bf(torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251 - 125)
+    got = ops.gemm(dev(a), dev(w), None, tile=1)
+    assert torch.equal(got.float().cpu(), w.float().t())
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_epilogues(ops, tile):
+    rs = np.random.RandomState(5)
+    B, Lr, N, K = 2, 150, 512, 256
+    M = B * Lr
+    a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
+    resid, hint = bf(rs_randn(rs, M, N)), bf(rs_randn(rs, M, N))
+    gate = bf(rs_randn(rs, B, N))
+    y = O.linear(a.float(), w.float(), b.float(), mode="bf16")
+    r = lambda t: t.to(torch.bfloat16).float()
+    # gelu
+    got = ops.gemm(dev(a), dev(w), dev(b), epilogue=ops.EPI_BIAS_GELU, tile=tile)
+    assert_bf16_close(got, O.gelu_tanh(y), ulps=2.0, atol=2e-3, what="gelu")
+    # residual
+    got = ops.gemm(dev(a), dev(w), dev(b), epilogue=ops.EPI_BIAS_RESID, resid=dev(resid), tile=tile)
+    assert_bf16_close(got, resid.float() + y, ulps=2.0, atol=4e-3, what="resid")
+    # gate + residual, in place on the residual buffer (as the engine uses it)
+    buf = dev(resid).clone()
+    ops.gemm(dev(a), dev(w), dev(b), epilogue=ops.EPI_BIAS_GATE_RESID, resid=buf, gate=dev(gate), rows_per_batch=Lr,
+             out=buf, tile=tile)
+    want = resid.float() + r(y * gate.float().repeat_interleave(Lr, 0))
+    assert_bf16_close(buf, want, ulps=2.0, atol=8e-3, what="gate")
+    # gate + residual + hint
+    got = ops.gemm(dev(a), dev(w), dev(b), epilogue=ops.EPI_BIAS_GATE_RESID, resid=dev(resid), gate=dev(gate),
+                   rows_per_batch=Lr, hint=dev(hint), hint_scale=0.6, tile=tile)
+    want = r(want) + r(hint.float() * 0.6)
+    assert_bf16_close(got, want, ulps=2.0, atol=1.2e-2, what="gate+hint")
+
+
+def test_gemm_strided_output(ops):
+    """q/k/v projections write column slices of one [M, 3d] buffer (ldc = 3d)."""
+    rs = np.random.RandomState(9)
+    M, d = 200, 256
+    a = bf(rs_randn(rs, M, d))
+    ws = [bf(rs_randn(rs, d, d, scale=d ** -0.5)) for _ in range(3)]
+    out = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device="cuda")
+    for i, w in enumerate(ws):
+        ops.gemm(dev(a), dev(w), None, out=out[:, i * d:(i + 1) * d])
+    want = torch.cat([O.linear(a.float(), w.float(), None) for w in ws], 1)
+    assert_bf16_close(out, want, ulps=1.01, atol=2e-3, what="strided")
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,Lq,Lk,k_len", [(2, 2, 200, 200, 150), (1, 3, 130, 1000, 0), (2, 1, 72, 48, 0),
+                                             (1, 2, 129, 64, 64), (1, 1, 64, 520, 513)])
+def test_attention(ops, B, H, Lq, Lk, k_len):
+    rs = np.random.RandomState(Lq + Lk)
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for L in (Lq, Lk, Lk))
+    want = O.attention(q.float(), k.float(), v.float(), None if k_len == 0 else [k_len] * B)
+    got = ops.attention(dev(q), dev(k), dev(v), k_len=k_len)
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before P.V (as flash-attn does): allow 2^-8 relative on top of output rounding
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="attention")
+    assert rel_l2(got, want) < 6e-3
+
+
+def test_attention_packed_qkv_layout(ops):
+    """The engine reads q, k, v as strided views of one [B*L, 3d] buffer."""
+    rs = np.random.RandomState(3)
+    B, L, H = 2, 96, 2
+    d = H * 128
+    qkv = bf(rs_randn(rs, B, L, 3 * d))
+    g = dev(qkv)
+    q, k, v = (g[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128)) for i in range(3))
+    got = ops.attention(q, k, v, k_len=90)
+    qc, kc, vc = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128)).float() for i in range(3))
+    want = O.attention(qc, kc, vc, [90, 90])
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="packed")
+
+
+def test_attention_large_logits_rescale(ops):
+    """Force the online-softmax rescale: one key row far larger than the running max, late in the sequence."""
+    rs = np.random.RandomState(4)
+    B, H, L = 1, 1, 320
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for _ in range(3))
+    k[0, 300, 0] = q[0, 7, 0] * 4.0          # huge logit for query 7 at key 300 (5th tile)
+    k[0, 10, 0] = q[0, 100, 0] * 3.0
+    want = O.attention(q.float(), k.float(), v.float(), None)
+    got = ops.attention(dev(q), dev(k), dev(v))
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="rescale")
+
+
+# ----------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("dim", [256, 1536, 5120])
+def test_layernorm_modulate(ops, dim):
+    rs = np.random.RandomState(dim)
+    B, Lr = 2, 37
+    x = bf(rs_randn(rs, B * Lr, dim, scale=2.0) + 0.5)
+    mod = bf(rs_randn(rs, B, 6, dim, scale=0.3))
+    g = dev(mod)
+    got = ops.layernorm_modulate(dev(x), g[:, 1], g[:, 0], Lr)
+    xb = x.float().view(B, Lr, dim)
+    r = lambda t: t.to(torch.bfloat16).float()
+    want = r(r(O.layer_norm(xb, mode="bf16") * r(1 + mod[:, 1:2].float())) + mod[:, 0:1].float())
+    assert_bf16_close(got, want.view(B * Lr, dim), ulps=1.01, atol=1e-2, what="ln modulate")
+
+
+def test_layernorm_affine(ops):
+    rs = np.random.RandomState(1)
+    dim = 5120
+    x = bf(rs_randn(rs, 50, dim, scale=3.0))
+    w, b = bf(1 + 0.1 * rs_randn(rs, dim)), bf(0.1 * rs_randn(rs, dim))
+    got = ops.layernorm_affine(dev(x), dev(w), dev(b))
+    want = O.layer_norm(x.float(), w.float(), b.float())
+    assert_bf16_close(got, want, ulps=1.01, atol=2e-3, what="ln affine")
+
+
+@pytest.mark.parametrize("dim,heads", [(256, 2), (5120, 40)])
+def test_rmsnorm_rope(ops, dim, heads):
+    rs = np.random.RandomState(dim + 1)
+    B, grid = 2, (3, 4, 6)
+    Lr = 80                                   # 72 lattice tokens + 8 padded rows (pass through un-rotated)
+    x = bf(rs_randn(rs, B, Lr, dim, scale=1.5))
+    w = bf(1 + 0.1 * rs_randn(rs, dim))
+    tab = O.rope_table(128)
+    want = O.rope_apply(O.rms_norm(x.float(), w.float(), 1e-6, mode="bf16").view(B, Lr, heads, 128),
+                        [grid] * B, tab, mode="bf16").view(B * Lr, dim)
+    g = dev(x).view(B * Lr, dim).clone()
+    ops.rmsnorm_rope_(g, dev(w), 1e-6, ops.rope_table_device(tab, "cuda"), grid, token_offset=0, rows_per_batch=Lr)
+    assert_bf16_close(g, want, ulps=1.01, atol=6e-3, what="rmsnorm+rope")
+    # sequence-parallel chunk: rows [40, 80) with token_offset 40 give the same values
+    g2 = dev(x)[:, 40:].reshape(B * 40, dim).clone()
+    ops.rmsnorm_rope_(g2, dev(w), 1e-6, ops.rope_table_device(tab, "cuda"), grid, token_offset=40, rows_per_batch=40)
+    assert torch.equal(g2.view(B, 40, dim), g.view(B, Lr, dim)[:, 40:])
+    # no-rope variant (cross-attention q / k)
+    g3 = dev(x).view(B * Lr, dim).clone()
+    ops.rmsnorm_rope_(g3, dev(w), 1e-6)
+    assert_bf16_close(g3, O.rms_norm(x.float(), w.float(), 1e-6, mode="bf16").view(B * Lr, dim), ulps=1.01,
+                      atol=4e-3, what="rmsnorm")

@@ -1,0 +1,95 @@
+"""ctypes binding of libvcengine.so (include/vcengine.h).
+
+This is the binding a maintainer of the reference would add (INTEGRATION.md shows it verbatim).
+There is deliberately no fallback: if the shared library is missing or fails to load, importing the
+compute path raises, so a run can never silently proceed on a non-HIP path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcengine.so")
+
+VC_OK = 0
+VC_E_INVALID, VC_E_HIP, VC_E_STATE, VC_E_NOMEM, VC_E_UNSUPPORTED = -1, -2, -3, -4, -5
+VC_FWD_RUN_MAIN_BLOCKS, VC_FWD_STORE_RESIDUAL, VC_FWD_USE_RESIDUAL = 1, 2, 4
+VC_MAX_GEOADA_LAYERS = 64
+VC_ABI_VERSION = 1
+
+
+class vc_config(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("ffn_dim", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32),
+                ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("geoada_in_dim", C.c_int32),
+                ("text_dim", C.c_int32), ("text_len", C.c_int32), ("freq_dim", C.c_int32),
+                ("eps", C.c_float), ("num_geoada_layers", C.c_int32),
+                ("geoada_layers", C.c_int32 * VC_MAX_GEOADA_LAYERS)]
+
+
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+# every symbol include/vcengine.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "vc_abi_version": (_I, []),
+    "vc_last_error": (C.c_char_p, [_P]),
+    "vc_create": (_I, [C.POINTER(vc_config), C.POINTER(_P)]),
+    "vc_destroy": (None, [_P]),
+    "vc_load_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L)]),
+    "vc_missing_weights": (_I, [_P]),
+    "vc_set_rope_table": (_I, [_P, C.POINTER(C.c_double), _I, _I]),
+    "vc_sp_init": (_I, [_P, _I, _I, ALL_TO_ALL_FN, ALL_GATHER_FN, _P]),
+    "vc_prepare_video": (_I, [_P, _P, C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _P]),
+    "vc_forward": (_I, [_P, _P, _P, _P, _F, C.c_uint32, _P]),
+    "vc_time_embedding": (_I, [_P, _P, _I, _P, _P]),
+    "vc_workspace_bytes": (_L, [_P]),
+    "vc_op_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _L, _F, _I, _P]),
+    "vc_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
+                             C.POINTER(_L), _I, _F, _P]),
+    "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
+    "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvcengine.so (once).  Raises RuntimeError if it is not built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C versecrafter_amd/csrc`).  versecrafter_amd has no non-HIP fallback.")
+    # torch must own the HIP runtime first so that both share one libamdhip64 (same soname) instance
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vc_abi_version() != VC_ABI_VERSION:
+        raise RuntimeError("libvcengine ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class VcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvcengine error {code}: {msg}")
+        self.code = code
+
+
+def check(code, handle=None):
+    if code == VC_OK:
+        return
+    msg = load().vc_last_error(handle)
+    msg = msg.decode() if msg else ""
+    if code == VC_E_INVALID:
+        raise ValueError(f"libvcengine: {msg}")
+    raise VcError(code, msg)
+
+
+def i64x3(a, b, c):
+    return (C.c_int64 * 3)(a, b, c)

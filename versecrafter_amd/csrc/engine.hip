@@ -1,0 +1,687 @@
+// libvcengine: the denoise-step engine behind include/vcengine.h.
+//
+// vc_forward restates VerseCrafterWanTransformer3DModel.forward
+// (versecrafter/models/wan_transformer3d_versecrafter.py:295-442) as a fixed sequence of HIP kernel launches
+// on one stream, with these departures from the reference's execution (results unchanged):
+//   * step-invariant work is hoisted into vc_prepare_video: geoada_patch_embedding (VC.py:262), text_embedding
+//     (VC.py:358-363) and every block's cross-attention k/v projections (WT.py:421-422);
+//   * the GeoAdapter chain is interleaved with the main chain (adapter block n runs right before the main block
+//     that consumes hint n), so one hint buffer is live instead of the torch.stack/unbind pile of VC.py:117-124;
+//     the hint add of VC.py:147 is fused into that main block's FFN-2 GEMM epilogue;
+//   * on a TeaCache-skipped step (VC.py:390-396) the adapter chain is not run at all (its output is unused);
+//   * q/k/v are written into one [M, 3d] buffer that the attention kernel reads through strides.
+// Sequence parallelism (WT.py:901-921, VC.py:269-270, 366-367, 432-433): contiguous token chunk per rank,
+// Ulysses head-scatter all-to-all around self-attention through host callbacks (torch.distributed / RCCL).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vcengine.h"
+#include "vc_kernels.h"
+
+extern int vc_gemm_tile_override;
+
+namespace {
+
+struct WeightSlot {
+    std::vector<int64_t> shape;
+    const void* ptr = nullptr;
+};
+
+struct BlockW {
+    const void *modulation;
+    const void *sa_q_w, *sa_q_b, *sa_k_w, *sa_k_b, *sa_v_w, *sa_v_b, *sa_o_w, *sa_o_b, *sa_nq, *sa_nk;
+    const void *ca_q_w, *ca_q_b, *ca_k_w, *ca_k_b, *ca_v_w, *ca_v_b, *ca_o_w, *ca_o_b, *ca_nq, *ca_nk;
+    const void *n3_w, *n3_b, *f0_w, *f0_b, *f2_w, *f2_b;
+    const void *before_w = nullptr, *before_b = nullptr, *after_w = nullptr, *after_b = nullptr;
+    void *ck = nullptr, *cv = nullptr;   // cached cross-attention K / V  [B*text_len, dim]
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct vc_engine {
+    vc_config cfg;
+    std::vector<int> geoada_layers;
+    std::vector<int> layer_to_hint;   // size num_layers, -1 = none
+    std::unordered_map<std::string, WeightSlot> slots;
+    std::vector<std::string> slot_order;
+    bool resolved = false;
+    std::vector<BlockW> blocks, gblocks;
+    const void *pe_w, *pe_b, *gpe_w, *gpe_b, *te0_w, *te0_b, *te2_w, *te2_b, *ti0_w, *ti0_b, *ti2_w, *ti2_b, *tp_w,
+        *tp_b, *head_mod, *head_w, *head_b;
+
+    float2* rope_dev = nullptr;
+
+    // sequence parallel
+    int P = 1, rank = 0;
+    vc_all_to_all_fn a2a = nullptr;
+    vc_all_gather_fn ag = nullptr;
+    void* cb_ctx = nullptr;
+
+    // prepared video
+    bool prepared = false;
+    int B = 0, T = 0, H = 0, W = 0, H2 = 0, W2 = 0, L = 0, Lpad = 0, Lloc = 0, M = 0, tok_off = 0;
+    bool have_residual = false;
+
+    // workspace
+    char* arena = nullptr;
+    int64_t arena_bytes = 0;
+    void *x, *c, *tb, *qkv, *attn, *hb, *hint, *c0, *x0, *resid, *patchA, *ctxpad, *ctxh, *ctx, *mod, *headmod, *ybuf,
+        *yfull, *a2a_send, *a2a_recv;
+    float *f_sin, *f_h, *f_e, *f_e0;
+    void* small = nullptr;   // fp32 scratch for vc_time_embedding before prepare
+
+    std::string err;
+};
+
+namespace {
+
+int fail(vc_engine* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) return fail(h, VC_E_HIP, "%s: %s", #expr, hipGetErrorString(_e));          \
+    } while (0)
+#define VCCHK(h, expr)                                                                                   \
+    do {                                                                                                 \
+        int _r = (expr);                                                                                 \
+        if (_r != VC_OK) {                                                                               \
+            hipError_t _e = hipGetLastError();                                                           \
+            return fail(h, _r, "%s failed (%d)%s%s", #expr, _r, _e != hipSuccess ? ": " : "",             \
+                        _e != hipSuccess ? hipGetErrorString(_e) : "");                                  \
+        }                                                                                                \
+    } while (0)
+
+void add_slot(vc_engine* h, const std::string& k, std::vector<int64_t> shape) {
+    h->slots[k].shape = std::move(shape);
+    h->slot_order.push_back(k);
+}
+
+void add_block_slots(vc_engine* h, const std::string& p) {
+    const int64_t d = h->cfg.dim, f = h->cfg.ffn_dim;
+    add_slot(h, p + "modulation", {1, 6, d});
+    for (const char* a : {"self_attn", "cross_attn"}) {
+        for (const char* l : {"q", "k", "v", "o"}) {
+            add_slot(h, p + a + "." + l + ".weight", {d, d});
+            add_slot(h, p + a + "." + l + ".bias", {d});
+        }
+        add_slot(h, p + a + ".norm_q.weight", {d});
+        add_slot(h, p + a + ".norm_k.weight", {d});
+    }
+    add_slot(h, p + "norm3.weight", {d});
+    add_slot(h, p + "norm3.bias", {d});
+    add_slot(h, p + "ffn.0.weight", {f, d});
+    add_slot(h, p + "ffn.0.bias", {f});
+    add_slot(h, p + "ffn.2.weight", {d, f});
+    add_slot(h, p + "ffn.2.bias", {d});
+}
+
+const void* W(vc_engine* h, const std::string& k) { return h->slots.at(k).ptr; }
+
+void resolve_block(vc_engine* h, const std::string& p, BlockW& b) {
+    b.modulation = W(h, p + "modulation");
+    b.sa_q_w = W(h, p + "self_attn.q.weight"); b.sa_q_b = W(h, p + "self_attn.q.bias");
+    b.sa_k_w = W(h, p + "self_attn.k.weight"); b.sa_k_b = W(h, p + "self_attn.k.bias");
+    b.sa_v_w = W(h, p + "self_attn.v.weight"); b.sa_v_b = W(h, p + "self_attn.v.bias");
+    b.sa_o_w = W(h, p + "self_attn.o.weight"); b.sa_o_b = W(h, p + "self_attn.o.bias");
+    b.sa_nq = W(h, p + "self_attn.norm_q.weight"); b.sa_nk = W(h, p + "self_attn.norm_k.weight");
+    b.ca_q_w = W(h, p + "cross_attn.q.weight"); b.ca_q_b = W(h, p + "cross_attn.q.bias");
+    b.ca_k_w = W(h, p + "cross_attn.k.weight"); b.ca_k_b = W(h, p + "cross_attn.k.bias");
+    b.ca_v_w = W(h, p + "cross_attn.v.weight"); b.ca_v_b = W(h, p + "cross_attn.v.bias");
+    b.ca_o_w = W(h, p + "cross_attn.o.weight"); b.ca_o_b = W(h, p + "cross_attn.o.bias");
+    b.ca_nq = W(h, p + "cross_attn.norm_q.weight"); b.ca_nk = W(h, p + "cross_attn.norm_k.weight");
+    b.n3_w = W(h, p + "norm3.weight"); b.n3_b = W(h, p + "norm3.bias");
+    b.f0_w = W(h, p + "ffn.0.weight"); b.f0_b = W(h, p + "ffn.0.bias");
+    b.f2_w = W(h, p + "ffn.2.weight"); b.f2_b = W(h, p + "ffn.2.bias");
+}
+
+int resolve(vc_engine* h) {
+    if (h->resolved) return VC_OK;
+    for (auto& k : h->slot_order)
+        if (!h->slots[k].ptr) return fail(h, VC_E_STATE, "weight '%s' was never loaded (vc_load_weight)", k.c_str());
+    h->blocks.resize(h->cfg.num_layers);
+    for (int i = 0; i < h->cfg.num_layers; ++i) resolve_block(h, "blocks." + std::to_string(i) + ".", h->blocks[i]);
+    h->gblocks.resize(h->geoada_layers.size());
+    for (size_t n = 0; n < h->geoada_layers.size(); ++n) {
+        const std::string p = "geoada_blocks." + std::to_string(n) + ".";
+        resolve_block(h, p, h->gblocks[n]);
+        if (n == 0) {
+            h->gblocks[n].before_w = W(h, p + "before_proj.weight");
+            h->gblocks[n].before_b = W(h, p + "before_proj.bias");
+        }
+        h->gblocks[n].after_w = W(h, p + "after_proj.weight");
+        h->gblocks[n].after_b = W(h, p + "after_proj.bias");
+    }
+    h->pe_w = W(h, "patch_embedding.weight"); h->pe_b = W(h, "patch_embedding.bias");
+    h->gpe_w = W(h, "geoada_patch_embedding.weight"); h->gpe_b = W(h, "geoada_patch_embedding.bias");
+    h->te0_w = W(h, "text_embedding.0.weight"); h->te0_b = W(h, "text_embedding.0.bias");
+    h->te2_w = W(h, "text_embedding.2.weight"); h->te2_b = W(h, "text_embedding.2.bias");
+    h->ti0_w = W(h, "time_embedding.0.weight"); h->ti0_b = W(h, "time_embedding.0.bias");
+    h->ti2_w = W(h, "time_embedding.2.weight"); h->ti2_b = W(h, "time_embedding.2.bias");
+    h->tp_w = W(h, "time_projection.1.weight"); h->tp_b = W(h, "time_projection.1.bias");
+    h->head_mod = W(h, "head.modulation"); h->head_w = W(h, "head.head.weight"); h->head_b = W(h, "head.head.bias");
+    h->resolved = true;
+    return VC_OK;
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+VcGemmParams gemm(const void* A, int64_t lda, const void* Wt, const void* bias, void* C, int64_t ldc, int M, int N,
+                  int K, int epi = VC_EPI_BIAS) {
+    VcGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.epilogue = epi; p.valid_rows = -1;
+    return p;
+}
+
+// time embedding (VC.py:347-354): sinusoid -> Linear -> SiLU -> Linear = e ; SiLU -> Linear = e0 ; all fp32
+int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, float* f_e, float* f_e0, hipStream_t s) {
+    const int d = h->cfg.dim;
+    VCCHK(h, vc_launch_sinusoid(t, f_sin, B, h->cfg.freq_dim, s));
+    VCCHK(h, vc_launch_small_linear(f_sin, h->ti0_w, h->ti0_b, f_h, B, d, h->cfg.freq_dim, 0, s));
+    VCCHK(h, vc_launch_small_linear(f_h, h->ti2_w, h->ti2_b, f_e, B, d, d, 1, s));
+    VCCHK(h, vc_launch_small_linear(f_e, h->tp_w, h->tp_b, f_e0, B, 6 * d, d, 1, s));
+    return VC_OK;
+}
+
+// self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into h->attn
+int self_attention(vc_engine* h, hipStream_t s) {
+    const int d = h->cfg.dim, N = h->cfg.num_heads, B = h->B, Lloc = h->Lloc, P = h->P;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.scale = 1.0f / sqrtf(128.0f);
+    a.B = B;
+    if (P == 1) {
+        const char* q = (const char*)h->qkv;
+        a.q = q; a.k = q + (int64_t)d * 2; a.v = q + (int64_t)2 * d * 2;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * 3 * d;
+        a.q_ts = a.k_ts = a.v_ts = 3 * d;
+        a.q_hs = a.k_hs = a.v_hs = 128;
+        a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
+        a.H = N; a.Lq = Lloc; a.Lk = Lloc; a.k_len = h->L;
+        VCCHK(h, vc_launch_attention(a, s));
+        return VC_OK;
+    }
+    // ---- Ulysses: scatter heads / gather sequence, attend over the full sequence with N/P heads, and back ----
+    const int Nl = N / P;
+    const int64_t hd = (int64_t)Nl * 128;            // columns per peer
+    const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
+    for (int dst = 0; dst < P; ++dst)
+        for (int w = 0; w < 3; ++w)
+            VCCHK(h, vc_launch_copy_strided((const char*)h->qkv + ((int64_t)w * d + dst * hd) * 2,
+                                            (char*)h->a2a_send + ((int64_t)(dst * 3 + w) * blk) * 2, B * Lloc,
+                                            (int)hd, 3 * d, hd, s));
+    if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, 3 * blk * 2, (void*)s) != 0)
+        return fail(h, VC_E_STATE, "all_to_all callback failed (q/k/v)");
+    // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
+    const char* r = (const char*)h->a2a_recv;
+    a.q = r; a.k = r + blk * 2; a.v = r + 2 * blk * 2;
+    a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * hd;
+    a.q_ts = a.k_ts = a.v_ts = hd;
+    a.q_hs = a.k_hs = a.v_hs = 128;
+    a.seg_len = Lloc;
+    a.q_ss = a.k_ss = a.v_ss = 3 * blk;
+    // out (send buffer of the return exchange): [P_dst][B][Lloc][Nl][128]
+    a.out = h->a2a_send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
+    a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
+    VCCHK(h, vc_launch_attention(a, s));
+    if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, blk * 2, (void*)s) != 0)
+        return fail(h, VC_E_STATE, "all_to_all callback failed (o)");
+    // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
+    for (int src = 0; src < P; ++src)
+        VCCHK(h, vc_launch_copy_strided((const char*)h->a2a_recv + (int64_t)src * blk * 2,
+                                        (char*)h->attn + (int64_t)src * hd * 2, B * Lloc, (int)hd, hd, d, s));
+    return VC_OK;
+}
+
+// WanAttentionBlock.forward (WT.py:564-611) on stream buffer xs, in place.  hint (optional): VC.py:146-147.
+int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, hipStream_t s) {
+    const int d = h->cfg.dim, f = h->cfg.ffn_dim, M = h->M, B = h->B, Lloc = h->Lloc, TL = h->cfg.text_len;
+    const float eps = h->cfg.eps;
+    const char* mod = (const char*)h->mod;
+    auto modp = [&](int j) { return (const void*)(mod + (int64_t)j * d * 2); };
+    // e = modulation + e0  (WT.py:588)
+    VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, h->mod, B, 6, d, 6 * d, d, s));
+    // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
+    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s));
+    // q, k, v projections into [M, 3d]  (WT.py:385-387)
+    {
+        VcGemmParams g = gemm(h->tb, d, w.sa_q_w, w.sa_q_b, h->qkv, 3 * d, M, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+        g = gemm(h->tb, d, w.sa_k_w, w.sa_k_b, (char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+        g = gemm(h->tb, d, w.sa_v_w, w.sa_v_b, (char*)h->qkv + (int64_t)2 * d * 2, 3 * d, M, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)
+    VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
+    VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s));
+    VCCHK(h, vc_launch_rmsnorm_rope((char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s));
+    {
+        int r = self_attention(h, s);
+        if (r != VC_OK) return r;
+    }
+    // x = x + o(attn) * e2  (WT.py:404, 595)
+    {
+        VcGemmParams g = gemm(h->attn, d, w.sa_o_w, w.sa_o_b, xs, d, M, d, d, VC_EPI_BIAS_GATE_RESID);
+        g.resid = xs; g.ldr = d; g.gate = modp(2); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // cross attention: x = x + o(attn(rms(q(norm3(x))), K, V))  (WT.py:600, 410-436)
+    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s));
+    {
+        VcGemmParams g = gemm(h->tb, d, w.ca_q_w, w.ca_q_b, h->qkv, d, M, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, d, M, d, w.ca_nq, eps, nullptr, nullptr, s));
+    {
+        VcAttnParams a;
+        memset(&a, 0, sizeof a);
+        a.scale = 1.0f / sqrtf(128.0f);
+        a.q = h->qkv; a.q_bs = (int64_t)Lloc * d; a.q_ts = d; a.q_hs = 128;
+        a.k = w.ck; a.k_bs = (int64_t)TL * d; a.k_ts = d; a.k_hs = 128;
+        a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
+        a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
+        a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
+        VCCHK(h, vc_launch_attention(a, s));
+        VcGemmParams g = gemm(h->attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
+        g.resid = xs; g.ldr = d;
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // ffn: x = x + ffn(norm2(x) * (1 + e4) + e3) * e5  (WT.py:603-607)  [+ hint * scale, VC.py:147]
+    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s));
+    {
+        VcGemmParams g = gemm(h->tb, d, w.f0_w, w.f0_b, h->hb, f, M, f, d, VC_EPI_BIAS_GELU);
+        VCCHK(h, vc_launch_gemm(g, s));
+        g = gemm(h->hb, f, w.f2_w, w.f2_b, xs, d, M, d, f, VC_EPI_BIAS_GATE_RESID);
+        g.resid = xs; g.ldr = d; g.gate = modp(5); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
+        g.hint = hint; g.ldh = d; g.hint_scale = hint_scale;
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    return VC_OK;
+}
+
+void free_arena(vc_engine* h) {
+    if (h->arena) (void)hipFree(h->arena);
+    h->arena = nullptr;
+    h->arena_bytes = 0;
+    h->prepared = false;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int vc_abi_version(void) { return VC_ABI_VERSION; }
+
+const char* vc_last_error(const vc_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vc_create(const vc_config* cfg, vc_engine** out) {
+    if (!cfg || !out) return fail(nullptr, VC_E_INVALID, "vc_create: null argument");
+    *out = nullptr;
+    if (cfg->dim <= 0 || cfg->num_heads <= 0 || cfg->dim % cfg->num_heads || cfg->dim / cfg->num_heads != 128)
+        return fail(nullptr, VC_E_UNSUPPORTED, "vc_create: head dim must be 128 (dim=%d heads=%d)", cfg->dim,
+                    cfg->num_heads);
+    if (cfg->dim % 64 || cfg->ffn_dim % 64 || cfg->text_dim % 64 || (cfg->in_dim * 4) % 64 ||
+        (cfg->geoada_in_dim * 4) % 64 || cfg->freq_dim % 8 || cfg->dim > 8192)
+        return fail(nullptr, VC_E_UNSUPPORTED, "vc_create: dims must be multiples of 64 (K of every GEMM)");
+    if (cfg->num_layers <= 0 || cfg->text_len <= 0 || cfg->out_dim <= 0 || (cfg->out_dim * 4) % 4)
+        return fail(nullptr, VC_E_INVALID, "vc_create: bad config");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, VC_E_HIP, "vc_create: no HIP device (this library has no CPU path)");
+    vc_engine* h = new vc_engine();
+    h->cfg = *cfg;
+    if (cfg->num_geoada_layers > 0) {
+        if (cfg->num_geoada_layers > VC_MAX_GEOADA_LAYERS) { delete h; return fail(nullptr, VC_E_INVALID, "too many geoada layers"); }
+        h->geoada_layers.assign(cfg->geoada_layers, cfg->geoada_layers + cfg->num_geoada_layers);
+    } else {
+        for (int i = 0; i < cfg->num_layers; i += 2) h->geoada_layers.push_back(i);     // VC.py:175
+    }
+    bool has0 = false, asc = true;
+    for (size_t i = 0; i < h->geoada_layers.size(); ++i) {
+        has0 |= h->geoada_layers[i] == 0;
+        if (i && h->geoada_layers[i] <= h->geoada_layers[i - 1]) asc = false;
+        if (h->geoada_layers[i] < 0 || h->geoada_layers[i] >= cfg->num_layers) asc = false;
+    }
+    if (!has0) { delete h; return fail(nullptr, VC_E_INVALID, "assert 0 in geoada_layers (VC.py:178)"); }
+    if (!asc) { delete h; return fail(nullptr, VC_E_UNSUPPORTED, "geoada_layers must be strictly ascending and < num_layers"); }
+    h->layer_to_hint.assign(cfg->num_layers, -1);
+    for (size_t n = 0; n < h->geoada_layers.size(); ++n) h->layer_to_hint[h->geoada_layers[n]] = (int)n;
+
+    const int64_t d = cfg->dim;
+    add_slot(h, "patch_embedding.weight", {d, cfg->in_dim, 1, 2, 2});
+    add_slot(h, "patch_embedding.bias", {d});
+    add_slot(h, "geoada_patch_embedding.weight", {d, cfg->geoada_in_dim, 1, 2, 2});
+    add_slot(h, "geoada_patch_embedding.bias", {d});
+    add_slot(h, "text_embedding.0.weight", {d, cfg->text_dim});
+    add_slot(h, "text_embedding.0.bias", {d});
+    add_slot(h, "text_embedding.2.weight", {d, d});
+    add_slot(h, "text_embedding.2.bias", {d});
+    add_slot(h, "time_embedding.0.weight", {d, cfg->freq_dim});
+    add_slot(h, "time_embedding.0.bias", {d});
+    add_slot(h, "time_embedding.2.weight", {d, d});
+    add_slot(h, "time_embedding.2.bias", {d});
+    add_slot(h, "time_projection.1.weight", {6 * d, d});
+    add_slot(h, "time_projection.1.bias", {6 * d});
+    add_slot(h, "head.modulation", {1, 2, d});
+    add_slot(h, "head.head.weight", {(int64_t)cfg->out_dim * 4, d});
+    add_slot(h, "head.head.bias", {(int64_t)cfg->out_dim * 4});
+    for (int i = 0; i < cfg->num_layers; ++i) add_block_slots(h, "blocks." + std::to_string(i) + ".");
+    for (size_t n = 0; n < h->geoada_layers.size(); ++n) {
+        const std::string p = "geoada_blocks." + std::to_string(n) + ".";
+        add_block_slots(h, p);
+        if (n == 0) {
+            add_slot(h, p + "before_proj.weight", {d, d});
+            add_slot(h, p + "before_proj.bias", {d});
+        }
+        add_slot(h, p + "after_proj.weight", {d, d});
+        add_slot(h, p + "after_proj.bias", {d});
+    }
+    // fp32 scratch for the time embedding (B <= 8)
+    const int64_t small_bytes = 8 * (int64_t)(cfg->freq_dim + 2 * d + 6 * d) * 4;
+    if (hipMalloc(&h->small, small_bytes) != hipSuccess) { delete h; return fail(nullptr, VC_E_NOMEM, "hipMalloc(time scratch) failed"); }
+    *out = h;
+    return VC_OK;
+}
+
+void vc_destroy(vc_engine* h) {
+    if (!h) return;
+    free_arena(h);
+    if (h->rope_dev) (void)hipFree(h->rope_dev);
+    if (h->small) (void)hipFree(h->small);
+    delete h;
+}
+
+int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype, int ndim, const int64_t* shape) {
+    if (!h || !key || !dev_ptr || !shape) return fail(h, VC_E_INVALID, "vc_load_weight: null argument");
+    if (dtype != 0) return fail(h, VC_E_UNSUPPORTED, "vc_load_weight(%s): only bf16 (dtype 0) weights", key);
+    auto it = h->slots.find(key);
+    if (it == h->slots.end()) return fail(h, VC_E_INVALID, "vc_load_weight: unexpected key '%s'", key);
+    const auto& want = it->second.shape;
+    bool same = (int)want.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = want[i] == shape[i];
+    if (!same) return fail(h, VC_E_INVALID, "vc_load_weight(%s): size mismatch", key);   // WT.py:1304-1307
+    if ((uintptr_t)dev_ptr % 16) return fail(h, VC_E_INVALID, "vc_load_weight(%s): pointer not 16-byte aligned", key);
+    it->second.ptr = dev_ptr;
+    h->resolved = false;
+    h->prepared = false;   // cached cross-attention K/V depend on the weights
+    return VC_OK;
+}
+
+int vc_missing_weights(const vc_engine* h) {
+    if (!h) return -1;
+    int n = 0;
+    for (auto& kv : h->slots) n += kv.second.ptr == nullptr;
+    return n;
+}
+
+int vc_set_rope_table(vc_engine* h, const double* cis, int rows, int cols) {
+    if (!h || !cis) return fail(h, VC_E_INVALID, "vc_set_rope_table: null argument");
+    if (rows != 1024 || cols != 64) return fail(h, VC_E_UNSUPPORTED, "rope table must be [1024][64] (head dim 128)");
+    std::vector<float2> t((size_t)rows * cols);
+    for (size_t i = 0; i < t.size(); ++i) t[i] = make_float2((float)cis[2 * i], (float)cis[2 * i + 1]);
+    if (!h->rope_dev) HIPCHK(h, hipMalloc(&h->rope_dev, t.size() * sizeof(float2)));
+    HIPCHK(h, hipMemcpy(h->rope_dev, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return VC_OK;
+}
+
+int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_gather_fn ag, void* ctx) {
+    if (!h) return VC_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, VC_E_INVALID, "vc_sp_init: bad world/rank");
+    if (world > 1 && (!a2a || !ag)) return fail(h, VC_E_INVALID, "vc_sp_init: callbacks required for world > 1");
+    if (h->cfg.num_heads % world)
+        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
+    h->P = world; h->rank = rank; h->a2a = a2a; h->ag = ag; h->cb_ctx = ctx;
+    h->prepared = false;
+    return VC_OK;
+}
+
+int64_t vc_workspace_bytes(const vc_engine* h) { return h ? h->arena_bytes : 0; }
+
+int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const* text, const int32_t* text_lens,
+                     int B, int T, int H, int Wd, int seq_len, void* stream) {
+    if (!h || !geoada_context || !text || !text_lens) return fail(h, VC_E_INVALID, "vc_prepare_video: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || B > 8 || T <= 0 || H <= 0 || Wd <= 0 || (H & 1) || (Wd & 1))
+        return fail(h, VC_E_INVALID, "vc_prepare_video: bad shape B=%d T=%d H=%d W=%d", B, T, H, Wd);
+    if (T > 1024 || H / 2 > 1024 || Wd / 2 > 1024) return fail(h, VC_E_INVALID, "grid exceeds the 1024-row rope table");
+    if (!h->rope_dev) return fail(h, VC_E_STATE, "vc_set_rope_table must be called first");
+    { int r = resolve(h); if (r != VC_OK) return r; }
+    const vc_config& c = h->cfg;
+    const int d = c.dim, f = c.ffn_dim, TL = c.text_len, P = h->P;
+    const int L = T * (H / 2) * (Wd / 2);
+    int Lpad = seq_len;
+    if (P > 1) Lpad = (seq_len + P - 1) / P * P;                                   // WT.py:195-196
+    if (L > Lpad) return fail(h, VC_E_INVALID, "assert seq_lens.max() <= seq_len (WT.py:197): %d > %d", L, Lpad);
+    for (int i = 0; i < B; ++i)
+        if (text_lens[i] < 0 || text_lens[i] > TL || (text_lens[i] > 0 && !text[i]))
+            return fail(h, VC_E_INVALID, "prompt %d has %d tokens (text_len %d)", i, text_lens[i], TL);
+    const int Lloc = Lpad / P, M = B * Lloc;
+
+    // ---- workspace layout ----
+    free_arena(h);
+    const int nblk = c.num_layers + (int)h->geoada_layers.size();
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return o; };
+    const int64_t md = (int64_t)M * d * 2;
+    const int64_t o_x = take(md), o_c = take(md), o_tb = take(md), o_qkv = take(3 * md), o_attn = take(md),
+                  o_hb = take((int64_t)M * f * 2), o_hint = take(md), o_c0 = take(md), o_x0 = take(md),
+                  o_resid = take(md);
+    const int kmax = (c.geoada_in_dim > c.in_dim ? c.geoada_in_dim : c.in_dim) * 4;
+    const int64_t o_patch = take((int64_t)M * kmax * 2);
+    const int64_t o_ctxpad = take((int64_t)B * TL * c.text_dim * 2), o_ctxh = take((int64_t)B * TL * d * 2),
+                  o_ctx = take((int64_t)B * TL * d * 2);
+    const int64_t o_mod = take((int64_t)B * 6 * d * 2), o_headmod = take((int64_t)B * 2 * d * 2);
+    const int64_t yb = (int64_t)M * c.out_dim * 4 * 2;
+    const int64_t o_y = take(yb), o_yfull = take(yb * P);
+    const int64_t o_send = take(P > 1 ? 3 * md : 256), o_recv = take(P > 1 ? 3 * md : 256);
+    const int64_t o_fsin = take((int64_t)B * c.freq_dim * 4), o_fh = take((int64_t)B * d * 4),
+                  o_fe = take((int64_t)B * d * 4), o_fe0 = take((int64_t)B * 6 * d * 4);
+    const int64_t kvb = (int64_t)B * TL * d * 2;
+    const int64_t o_kv = take(2 * kvb * nblk);
+    if (hipMalloc(&h->arena, off) != hipSuccess) {
+        (void)hipGetLastError();
+        h->arena = nullptr;
+        return fail(h, VC_E_NOMEM, "hipMalloc of %lld-byte workspace failed", (long long)off);
+    }
+    h->arena_bytes = off;
+    char* a = h->arena;
+    h->x = a + o_x; h->c = a + o_c; h->tb = a + o_tb; h->qkv = a + o_qkv; h->attn = a + o_attn; h->hb = a + o_hb;
+    h->hint = a + o_hint; h->c0 = a + o_c0; h->x0 = a + o_x0; h->resid = a + o_resid; h->patchA = a + o_patch;
+    h->ctxpad = a + o_ctxpad; h->ctxh = a + o_ctxh; h->ctx = a + o_ctx; h->mod = a + o_mod; h->headmod = a + o_headmod;
+    h->ybuf = a + o_y; h->yfull = a + o_yfull; h->a2a_send = a + o_send; h->a2a_recv = a + o_recv;
+    h->f_sin = (float*)(a + o_fsin); h->f_h = (float*)(a + o_fh); h->f_e = (float*)(a + o_fe);
+    h->f_e0 = (float*)(a + o_fe0);
+    for (int i = 0; i < nblk; ++i) {
+        BlockW& bw = i < c.num_layers ? h->blocks[i] : h->gblocks[i - c.num_layers];
+        bw.ck = a + o_kv + (int64_t)(2 * i) * kvb;
+        bw.cv = a + o_kv + (int64_t)(2 * i + 1) * kvb;
+    }
+    h->B = B; h->T = T; h->H = H; h->W = Wd; h->H2 = H / 2; h->W2 = Wd / 2; h->L = L; h->Lpad = Lpad; h->Lloc = Lloc;
+    h->M = M; h->tok_off = h->rank * Lloc; h->have_residual = false;
+
+    // ---- control-map patch embedding (VC.py:262-270): c0 = Conv3d(geoada_context), zero-padded rows ----
+    VCCHK(h, vc_launch_patchify(geoada_context, h->patchA, B, c.geoada_in_dim, T, H, Wd, Lloc, h->tok_off, s));
+    {
+        VcGemmParams g = gemm(h->patchA, c.geoada_in_dim * 4, h->gpe_w, h->gpe_b, h->c0, d, M, d, c.geoada_in_dim * 4);
+        g.rows_per_batch = Lloc;
+        int vr = L - h->tok_off; g.valid_rows = vr < 0 ? 0 : (vr > Lloc ? Lloc : vr);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // ---- text embedding (VC.py:358-363) ----
+    for (int i = 0; i < B; ++i)
+        VCCHK(h, vc_launch_pad_rows(text[i], (char*)h->ctxpad + (int64_t)i * TL * c.text_dim * 2, text_lens[i], TL,
+                                    c.text_dim, s));
+    {
+        VcGemmParams g = gemm(h->ctxpad, c.text_dim, h->te0_w, h->te0_b, h->ctxh, d, B * TL, d, c.text_dim,
+                              VC_EPI_BIAS_GELU);
+        VCCHK(h, vc_launch_gemm(g, s));
+        g = gemm(h->ctxh, d, h->te2_w, h->te2_b, h->ctx, d, B * TL, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // ---- cross-attention k / v of every block (WT.py:421-422) ----
+    for (int i = 0; i < nblk; ++i) {
+        BlockW& bw = i < c.num_layers ? h->blocks[i] : h->gblocks[i - c.num_layers];
+        VcGemmParams g = gemm(h->ctx, d, bw.ca_k_w, bw.ca_k_b, bw.ck, d, B * TL, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, vc_launch_rmsnorm_rope(bw.ck, d, B * TL, d, bw.ca_nk, c.eps, nullptr, nullptr, s));
+        g = gemm(h->ctx, d, bw.ca_v_w, bw.ca_v_b, bw.cv, d, B * TL, d, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    h->prepared = true;
+    return VC_OK;
+}
+
+int vc_time_embedding(vc_engine* h, const float* t, int B, float* e0_out, void* stream) {
+    if (!h || !t || !e0_out || B <= 0 || B > 8) return fail(h, VC_E_INVALID, "vc_time_embedding: bad argument");
+    { int r = resolve(h); if (r != VC_OK) return r; }
+    const int d = h->cfg.dim;
+    float* fs = (float*)h->small;
+    float* fh = fs + 8 * h->cfg.freq_dim;
+    float* fe = fh + 8 * d;
+    return time_embed(h, t, B, fs, fh, fe, e0_out, (hipStream_t)stream);
+}
+
+int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geoada_context_scale, uint32_t flags,
+               void* stream) {
+    if (!h || !x || !t || !out) return fail(h, VC_E_INVALID, "vc_forward: null argument");
+    if (!h->prepared) return fail(h, VC_E_STATE, "vc_forward before vc_prepare_video");
+    const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL,
+               use_res = flags & VC_FWD_USE_RESIDUAL;
+    if (run_main == use_res) return fail(h, VC_E_INVALID, "vc_forward: exactly one of RUN_MAIN_BLOCKS / USE_RESIDUAL");
+    if (use_res && !h->have_residual) return fail(h, VC_E_STATE, "vc_forward: no stored residual to re-use");
+    hipStream_t s = (hipStream_t)stream;
+    const vc_config& c = h->cfg;
+    const int d = c.dim, M = h->M, B = h->B, Lloc = h->Lloc;
+    const int64_t md = (int64_t)M * d * 2;
+
+    // ---- patch embedding (VC.py:340-344) + sequence chunk (VC.py:366-367) ----
+    VCCHK(h, vc_launch_patchify(x, h->patchA, B, c.in_dim, h->T, h->H, h->W, Lloc, h->tok_off, s));
+    {
+        VcGemmParams g = gemm(h->patchA, c.in_dim * 4, h->pe_w, h->pe_b, h->x, d, M, d, c.in_dim * 4);
+        g.rows_per_batch = Lloc;
+        int vr = h->L - h->tok_off; g.valid_rows = vr < 0 ? 0 : (vr > Lloc ? Lloc : vr);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    // ---- time embeddings (VC.py:347-354) ----
+    { int r = time_embed(h, t, B, h->f_sin, h->f_h, h->f_e, h->f_e0, s); if (r != VC_OK) return r; }
+
+    if (run_main) {
+        if (store_res) HIPCHK(h, hipMemcpyAsync(h->x0, h->x, md, hipMemcpyDeviceToDevice, s));
+        // c = before_proj(c0) + x   (VC.py:113-114)
+        {
+            const BlockW& g0 = h->gblocks[0];
+            VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
+            g.resid = h->x; g.ldr = d;
+            VCCHK(h, vc_launch_gemm(g, s));
+        }
+        size_t next_adapter = 0;
+        for (int i = 0; i < c.num_layers; ++i) {
+            const int hn = h->layer_to_hint[i];
+            if (hn >= 0) {
+                while ((int)next_adapter <= hn) {            // adapter block n, then hint_n = after_proj(c)
+                    const BlockW& gb = h->gblocks[next_adapter];
+                    int r = run_block(h, gb, h->c, nullptr, 0.f, s);
+                    if (r != VC_OK) return r;
+                    VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint, d, M, d, d);
+                    VCCHK(h, vc_launch_gemm(g, s));
+                    ++next_adapter;
+                }
+            }
+            int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint : nullptr, geoada_context_scale, s);
+            if (r != VC_OK) return r;
+        }
+        if (store_res) {                                     // previous_residual_cond = x - ori_x (VC.py:409)
+            VCCHK(h, vc_launch_sub(h->x, h->x0, h->resid, (int64_t)M * d, s));
+            h->have_residual = true;
+        }
+    } else {
+        VCCHK(h, vc_launch_axpy(h->x, h->resid, h->x, 1.0f, (int64_t)M * d, s));   // VC.py:396
+    }
+
+    // ---- head (WT.py:631-644) ----
+    VCCHK(h, vc_launch_modulation(h->head_mod, h->f_e, h->headmod, B, 2, d, d, 0, s));   // e broadcast over 2 rows
+    VCCHK(h, vc_launch_layernorm(h->x, h->tb, M, d, Lloc, c.eps, 0, (char*)h->headmod + (int64_t)d * 2, h->headmod,
+                                 2 * d, s));
+    {
+        VcGemmParams g = gemm(h->tb, d, h->head_w, h->head_b, h->ybuf, c.out_dim * 4, M, c.out_dim * 4, d);
+        VCCHK(h, vc_launch_gemm(g, s));
+    }
+    const void* y = h->ybuf;
+    if (h->P > 1) {                                          // VC.py:432-433
+        if (h->ag(h->cb_ctx, h->ybuf, h->yfull, (int64_t)M * c.out_dim * 4 * 2, (void*)s) != 0)
+            return fail(h, VC_E_STATE, "all_gather callback failed");
+        y = h->yfull;
+    }
+    VCCHK(h, vc_launch_unpatchify(y, out, B, c.out_dim, h->T, h->H2, h->W2, Lloc, s));
+    return VC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int vc_op_gemm_bf16(const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, const void* bias,
+                    int M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate,
+                    int64_t gate_bstride, int rows_per_batch, const void* hint, int64_t ldh, float hint_scale, int tile,
+                    void* stream) {
+    VcGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
+    p.epilogue = epilogue; p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_bstride = gate_bstride;
+    p.rows_per_batch = rows_per_batch; p.hint = hint; p.ldh = ldh; p.hint_scale = hint_scale; p.valid_rows = -1;
+    const int prev = vc_gemm_tile_override;
+    vc_gemm_tile_override = tile;
+    const int r = vc_launch_gemm(p, (hipStream_t)stream);
+    vc_gemm_tile_override = prev;
+    return r;
+}
+
+int vc_op_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                    const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, int k_len, float scale,
+                    void* stream) {
+    if (!qs || !ks || !vs || !os) return VC_E_INVALID;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale;
+    return vc_launch_attention(a, (hipStream_t)stream);
+}
+
+int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode, const void* p0,
+                    const void* p1, int64_t p_bstride, void* stream) {
+    return vc_launch_layernorm(x, y, rows, dim, rows_per_batch, eps, mode, p0, p1, p_bstride, (hipStream_t)stream);
+}
+
+int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps, const void* table,
+                       const int32_t* grid5, void* stream) {
+    VcRopeGrid g{0, 0, 0, 0, 0};
+    if (table) {
+        if (!grid5) return VC_E_INVALID;
+        g = VcRopeGrid{grid5[0], grid5[1], grid5[2], grid5[3], grid5[4]};
+    }
+    return vc_launch_rmsnorm_rope(x, ld, rows, dim, w, eps, (const float2*)table, table ? &g : nullptr,
+                                  (hipStream_t)stream);
+}
+
+}  // extern "C"

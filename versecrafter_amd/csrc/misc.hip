@@ -1,0 +1,223 @@
+// Small kernels of the denoise step: patchify / unpatchify gathers, the fp32 time-embedding MLPs,
+// modulation tables, bf16 elementwise helpers.  None of them is on the roofline-relevant part of the step.
+//
+//   patch_embedding (Conv3d k=s=(1,2,2) == GEMM over 2x2 patches)  wan_transformer3d.py:758-759, VC.py:199-201
+//   unpatchify                                                     wan_transformer3d.py:1127-1150
+//   sinusoidal_embedding_1d / time_embedding / time_projection     wan_transformer3d.py:39-49, 764-766; VC.py:347-354
+//   modulation + e                                                 wan_transformer3d.py:588, 641
+#include "vc_common.h"
+#include "vc_kernels.h"
+
+namespace {
+
+// thread = (b, c, tok): reads the 2x2 patch, writes 4 contiguous bf16 of row b*Lpad+tok at column c*4
+__global__ void patchify_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ A, int B, int C, int T, int H,
+                                int W, int Lrows, int tok_offset) {
+    const int H2 = H / 2, W2 = W / 2;
+    const int L = T * H2 * W2;
+    const int64_t total = (int64_t)B * C * Lrows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int li = (int)(i % Lrows);
+        const int tok = tok_offset + li;
+        const int c = (int)((i / Lrows) % C);
+        const int b = (int)(i / ((int64_t)Lrows * C));
+        uint2 o = make_uint2(0u, 0u);
+        if (tok < L) {
+            const int w2 = tok % W2, h2 = (tok / W2) % H2, f = tok / (W2 * H2);
+            const bf16_t* src = x + ((((int64_t)b * C + c) * T + f) * H + 2 * h2) * W + 2 * w2;
+            o.x = *(const uint32_t*)src;
+            o.y = *(const uint32_t*)(src + W);
+        }
+        *(uint2*)(A + ((int64_t)b * Lrows + li) * (C * 4) + c * 4) = o;
+    }
+}
+
+// thread = (b, c, tok): out[b, c, f, 2h+q, 2w+r] = y[b*Lpad + tok, (q*2+r)*C + c]
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int B, int C, int T,
+                                  int H2, int W2, int Lloc) {
+    const int L = T * H2 * W2;
+    const int64_t total = (int64_t)B * C * L;
+    const int H = 2 * H2, W = 2 * W2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tok = (int)(i % L);
+        const int c = (int)((i / L) % C);
+        const int b = (int)(i / ((int64_t)L * C));
+        const int w2 = tok % W2, h2 = (tok / W2) % H2, f = tok / (W2 * H2);
+        const int64_t row = (int64_t)(tok / Lloc) * B * Lloc + (int64_t)b * Lloc + tok % Lloc;
+        const bf16_t* src = y + row * (4 * C) + c;
+        bf16_t* dst = out + ((((int64_t)b * C + c) * T + f) * H + 2 * h2) * W + 2 * w2;
+        dst[0] = src[0];
+        dst[1] = src[C];
+        dst[W] = src[2 * C];
+        dst[W + 1] = src[3 * C];
+    }
+}
+
+constexpr int SL_MAXB = 8;
+// one wave per output n: y[b, n] = sum_k act(x[b, k]) * W[n, k] + bias[n]
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
+                                                           const bf16_t* __restrict__ bias, float* __restrict__ y,
+                                                           int B, int N, int K, int silu_input) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float acc[SL_MAXB];
+#pragma unroll
+    for (int b = 0; b < SL_MAXB; ++b) acc[b] = 0.f;
+    const bf16_t* wr = W + (int64_t)n * K;
+    for (int k = lane * 8; k < K; k += 512) {
+        float wf[8];
+        unpack8(*(const uint4*)(wr + k), wf);
+#pragma unroll
+        for (int b = 0; b < SL_MAXB; ++b) {
+            if (b < B) {
+                const float4 x0 = *(const float4*)(x + (int64_t)b * K + k);
+                const float4 x1 = *(const float4*)(x + (int64_t)b * K + k + 4);
+                float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = silu_input ? silu_f(xv[e]) : xv[e];
+                    acc[b] += a * wf[e];
+                }
+            }
+        }
+    }
+    const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+    for (int b = 0; b < SL_MAXB; ++b) {
+        if (b < B) {
+            const float s = wave_sum(acc[b]);
+            if (lane == 0) y[(int64_t)b * N + n] = s + bv;
+        }
+    }
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int freq_dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * freq_dim) return;
+    const int b = i / freq_dim, j = i % freq_dim, half = freq_dim / 2;
+    const int jj = j < half ? j : j - half;
+    const double w = pow(10000.0, -(double)jj / (double)half);
+    const double s = (double)t[b] * w;
+    out[i] = (float)(j < half ? cos(s) : sin(s));
+}
+
+__global__ void modulation_kernel(const bf16_t* __restrict__ mod, const float* __restrict__ e, bf16_t* __restrict__ out,
+                                  int B, int J, int dim, int64_t e_bstride, int64_t e_jstride) {
+    const int64_t total = (int64_t)B * J * dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % dim);
+        const int j = (int)((i / dim) % J);
+        const int b = (int)(i / ((int64_t)J * dim));
+        out[i] = (bf16_t)((float)mod[(int64_t)j * dim + col] + round_bf16(e[b * e_bstride + j * e_jstride + col]));
+    }
+}
+
+__global__ void axpy_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+                            float s, int64_t n8, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float fa[8], fb[8];
+        unpack8(*(const uint4*)(a + i * 8), fa);
+        unpack8(*(const uint4*)(b + i * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] = mode == 0 ? fa[e] + round_bf16(fb[e] * s) : fa[e] - fb[e];
+        *(uint4*)(out + i * 8) = pack8(fa);
+    }
+}
+
+__global__ void pad_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int len, int total, int dim8) {
+    const int64_t n = (int64_t)total * dim8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / dim8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < len) v = ((const uint4*)src)[i];
+        ((uint4*)dst)[i] = v;
+    }
+}
+
+__global__ void copy_strided_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols8,
+                                    int64_t src_ld, int64_t dst_ld) {
+    const int64_t n = (int64_t)rows * cols8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols8), c = (int)(i % cols8);
+        *(uint4*)(dst + (int64_t)r * dst_ld + c * 8) = *(const uint4*)(src + (int64_t)r * src_ld + c * 8);
+    }
+}
+
+inline int grid_for(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP; }
+
+}  // namespace
+
+int vc_launch_patchify(const void* x, void* A, int B, int C, int T, int H, int W, int Lrows, int tok_offset,
+                       hipStream_t s) {
+    if (!x || !A || B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Lrows <= 0 || tok_offset < 0) return VC_E_INVALID;
+    if ((H & 1) || (W & 1)) return VC_E_INVALID;
+    const int64_t n = (int64_t)B * C * Lrows;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)A, B, C, T,
+                       H, W, Lrows, tok_offset);
+    return ok();
+}
+
+int vc_launch_unpatchify(const void* y, void* out, int B, int C, int T, int H2, int W2, int Lloc, hipStream_t s) {
+    if (!y || !out || B <= 0 || C <= 0 || T <= 0 || H2 <= 0 || W2 <= 0 || Lloc <= 0) return VC_E_INVALID;
+    const int64_t n = (int64_t)B * C * T * H2 * W2;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)out, B,
+                       C, T, H2, W2, Lloc);
+    return ok();
+}
+
+int vc_launch_small_linear(const float* x, const void* W, const void* bias, float* y, int B, int N, int K,
+                           int silu_input, hipStream_t s) {
+    if (!x || !W || !y || B <= 0 || B > SL_MAXB || N <= 0 || K <= 0) return VC_E_INVALID;
+    if (K % 8) return VC_E_UNSUPPORTED;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, (const bf16_t*)W,
+                       (const bf16_t*)bias, y, B, N, K, silu_input);
+    return ok();
+}
+
+int vc_launch_sinusoid(const float* t, float* out, int B, int freq_dim, hipStream_t s) {
+    if (!t || !out || B <= 0 || freq_dim <= 0 || (freq_dim & 1)) return VC_E_INVALID;
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((B * freq_dim + 255) / 256), dim3(256), 0, s, t, out, B, freq_dim);
+    return ok();
+}
+
+int vc_launch_modulation(const void* mod, const float* e, void* out, int B, int J, int dim, int64_t e_bstride,
+                         int64_t e_jstride, hipStream_t s) {
+    if (!mod || !e || !out || B <= 0 || J <= 0 || dim <= 0) return VC_E_INVALID;
+    hipLaunchKernelGGL(modulation_kernel, dim3(grid_for((int64_t)B * J * dim, 256)), dim3(256), 0, s,
+                       (const bf16_t*)mod, e, (bf16_t*)out, B, J, dim, e_bstride, e_jstride);
+    return ok();
+}
+
+int vc_launch_axpy(const void* a, const void* b, void* out, float sc, int64_t n, hipStream_t st) {
+    if (!a || !b || !out || n <= 0 || n % 8) return VC_E_INVALID;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
+                       (bf16_t*)out, sc, n / 8, 0);
+    return ok();
+}
+
+int vc_launch_sub(const void* a, const void* b, void* out, int64_t n, hipStream_t st) {
+    if (!a || !b || !out || n <= 0 || n % 8) return VC_E_INVALID;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b,
+                       (bf16_t*)out, 0.f, n / 8, 1);
+    return ok();
+}
+
+int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, hipStream_t st) {
+    if (!dst || total <= 0 || dim <= 0 || dim % 8 || len < 0 || len > total || (len > 0 && !src)) return VC_E_INVALID;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((int64_t)total * dim / 8, 256)), dim3(256), 0, st,
+                       (const bf16_t*)src, (bf16_t*)dst, len, total, dim / 8);
+    return ok();
+}
+
+int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
+                           hipStream_t st) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || cols % 8 || src_ld % 8 || dst_ld % 8) return VC_E_INVALID;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((int64_t)rows * cols / 8, 256)), dim3(256), 0, st,
+                       (const bf16_t*)src, (bf16_t*)dst, rows, cols / 8, src_ld, dst_ld);
+    return ok();
+}

@@ -1,0 +1,181 @@
+// Row kernels (HBM-bound): fp32 LayerNorm + adaLN modulate / affine, and full-dim RMSNorm + 3-axis RoPE.
+//
+//   WanLayerNorm            wan_transformer3d.py:326-346  (fp32 stats, biased variance, eps 1e-6)
+//   adaLN modulate          wan_transformer3d.py:591, 603, 643   y = LN(x) * (1 + scale) + shift
+//   norm3 (affine)          wan_transformer3d.py:548-550, 600
+//   WanRMSNorm              wan_transformer3d.py:307-323  (reduction over the FULL model dim, not per head)
+//   rope_apply              wan_transformer3d.py:143-172  (adjacent pairs, [22|21|21] split of 64 freqs)
+//
+// One 64-lane wave owns one row; the row stays in registers between the statistics pass and the
+// normalise pass (one HBM read + one HBM write per element), 16-byte bf16x8 accesses per lane.
+// Rounding points follow the reference under bf16 autocast (LN output, rsqrt, each bf16 multiply/add).
+#include "vc_common.h"
+#include "vc_kernels.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                        int rows, int dim, int rows_per_batch, float eps, int mode,
+                                                        const bf16_t* __restrict__ p0,
+                                                        const bf16_t* __restrict__ p1, int64_t p_bstride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (row >= rows) return;
+    const bf16_t* xr = x + (int64_t)row * dim;
+    uint4 raw[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            raw[c] = *(const uint4*)(xr + idx);
+            float f[8];
+            unpack8(raw[c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            float f[8];
+            unpack8(raw[c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; v += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)dim + eps);
+    const int b = rows_per_batch > 0 ? row / rows_per_batch : 0;
+    const bf16_t* q0 = mode == 0 ? p0 + (int64_t)b * p_bstride : p0;   // scale (mode 0) | weight (mode 1)
+    const bf16_t* q1 = mode == 0 ? p1 + (int64_t)b * p_bstride : p1;   // shift (mode 0) | bias   (mode 1)
+    bf16_t* yr = y + (int64_t)row * dim;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            float f[8], a[8], bb[8];
+            unpack8(raw[c], f);
+            unpack8(*(const uint4*)(q0 + idx), a);
+            unpack8(*(const uint4*)(q1 + idx), bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = (f[e] - mean) * rstd;
+                if (mode == 0)   // bf16(bf16(LN) * bf16(1 + scale)) + shift
+                    f[e] = round_bf16(round_bf16(n) * round_bf16(1.0f + a[e])) + bb[e];
+                else             // fp32 affine inside F.layer_norm, one rounding at the end
+                    f[e] = n * a[e] + bb[e];
+            }
+            *(uint4*)(yr + idx) = pack8(f);
+        }
+    }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ x, int64_t ld, int rows, int dim,
+                                                           const bf16_t* __restrict__ w, float eps,
+                                                           const float2* __restrict__ table, VcRopeGrid grid,
+                                                           int use_rope) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (row >= rows) return;
+    bf16_t* xr = x + (int64_t)row * ld;
+    uint4 raw[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            raw[c] = *(const uint4*)(xr + idx);
+            float f[8];
+            unpack8(raw[c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    const float inv = round_bf16(rsqrtf(wave_sum(ss) / (float)dim + eps));   // rsqrt(...).to(bf16), WT.py:323
+
+    // RoPE multipliers: this lane's 4 pairs have the same in-head pair index j0..j0+3 in every chunk
+    float cs[4], sn[4];
+    bool rot = false;
+    if (use_rope) {
+        const int tok = grid.token_offset + (grid.rows_per_batch > 0 ? row % grid.rows_per_batch : row);
+        if (tok < grid.F * grid.H * grid.W) {
+            rot = true;
+            const int hw = grid.H * grid.W;
+            const int pf = tok / hw, ph = (tok / grid.W) % grid.H, pw = tok % grid.W;
+            const int j0 = (lane & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                const int pos = j < 22 ? pf : (j < 43 ? ph : pw);
+                const float2 t = table[pos * 64 + j];
+                cs[e] = t.x;
+                sn[e] = t.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            float f[8], ww[8];
+            unpack8(raw[c], f);
+            unpack8(*(const uint4*)(w + idx), ww);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = round_bf16(round_bf16(f[e] * inv) * ww[e]);
+            if (rot) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = f[2 * e], bq = f[2 * e + 1];
+                    f[2 * e] = a * cs[e] - bq * sn[e];
+                    f[2 * e + 1] = a * sn[e] + bq * cs[e];
+                }
+            }
+            *(uint4*)(xr + idx) = pack8(f);
+        }
+    }
+}
+
+}  // namespace
+
+int vc_launch_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
+                        const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream) {
+    if (!x || !y || !p0 || !p1 || rows <= 0 || dim <= 0) return VC_E_INVALID;
+    if (dim % 8 || dim > 8192 || (p_bstride % 8)) return VC_E_UNSUPPORTED;
+    const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+#define LN_LAUNCH(MC)                                                                                          \
+    hipLaunchKernelGGL(layernorm_kernel<MC>, grid, block, 0, stream, (const bf16_t*)x, (bf16_t*)y, rows, dim,  \
+                       rows_per_batch, eps, mode, (const bf16_t*)p0, (const bf16_t*)p1, p_bstride)
+    if (dim <= 512) LN_LAUNCH(1);
+    else if (dim <= 2048) LN_LAUNCH(4);
+    else if (dim <= 5120) LN_LAUNCH(10);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+int vc_launch_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps,
+                           const float2* rope_table, const VcRopeGrid* grid, hipStream_t stream) {
+    if (!x || !w || rows <= 0 || dim <= 0) return VC_E_INVALID;
+    if (dim % 8 || dim > 8192 || ld % 8) return VC_E_UNSUPPORTED;
+    const int use_rope = (rope_table && grid) ? 1 : 0;
+    if (use_rope && dim % 128) return VC_E_UNSUPPORTED;
+    VcRopeGrid g = use_rope ? *grid : VcRopeGrid{0, 0, 0, 0, 0};
+    if (use_rope && (g.F > 1024 || g.H > 1024 || g.W > 1024 || g.F <= 0 || g.H <= 0 || g.W <= 0)) return VC_E_INVALID;
+    const dim3 gr((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+#define RMS_LAUNCH(MC)                                                                                      \
+    hipLaunchKernelGGL(rmsnorm_rope_kernel<MC>, gr, block, 0, stream, (bf16_t*)x, ld, rows, dim,            \
+                       (const bf16_t*)w, eps, rope_table, g, use_rope)
+    if (dim <= 512) RMS_LAUNCH(1);
+    else if (dim <= 2048) RMS_LAUNCH(4);
+    else if (dim <= 5120) RMS_LAUNCH(10);
+    else RMS_LAUNCH(16);
+#undef RMS_LAUNCH
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}

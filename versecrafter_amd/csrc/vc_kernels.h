@@ -1,0 +1,89 @@
+// Internal launcher interface of libvcengine (host side).  Every launcher enqueues on the
+// given HIP stream, allocates nothing, never synchronises, and returns 0 or a VC_E_* code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// error codes (mirrored in include/vcengine.h)
+#define VC_OK 0
+#define VC_E_INVALID (-1)
+#define VC_E_HIP (-2)
+#define VC_E_STATE (-3)
+#define VC_E_NOMEM (-4)
+#define VC_E_UNSUPPORTED (-5)
+
+// ---- GEMM: C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]) ------------------------------
+enum VcEpilogue {
+    VC_EPI_BIAS = 0,        // C = acc + bias
+    VC_EPI_BIAS_GELU = 1,   // C = gelu_tanh(acc + bias)
+    VC_EPI_BIAS_RESID = 2,  // C = resid + (acc + bias)
+    VC_EPI_BIAS_GATE_RESID = 3,  // C = resid + (acc + bias) * gate[b, n]  (+ hint * hint_scale)
+};
+
+struct VcGemmParams {
+    const void* A;    int64_t lda;   // bf16 [M, K]
+    const void* W;    int64_t ldw;   // bf16 [N, K]  (nn.Linear weight layout)
+    void* C;          int64_t ldc;   // bf16 [M, N]
+    const void* bias;                // bf16 [N] or nullptr
+    int M, N, K;
+    int epilogue;
+    const void* resid; int64_t ldr;  // bf16 [M, N] (may alias C)
+    const void* gate;  int64_t gate_bstride;  // bf16, gate[b*gate_bstride + n], b = m / rows_per_batch
+    const void* hint;  int64_t ldh;  float hint_scale;  // optional second residual (GATE_RESID only)
+    int rows_per_batch;              // rows per sample (for gate and valid_rows); 0 -> M
+    int valid_rows;                  // >= 0: rows with (m % rows_per_batch) >= valid_rows are written as 0; < 0: off
+};
+int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream);
+
+// ---- attention: out[b, i, h, :] = softmax(q k^T * scale) v ----------------------------------
+struct VcAttnParams {
+    const void* q; int64_t q_bs, q_ts, q_hs;   // element strides: batch, token, head (D=128 contiguous)
+    const void* k; int64_t k_bs, k_ts, k_hs;
+    const void* v; int64_t v_bs, v_ts, v_hs;
+    void* out;     int64_t o_bs, o_ts, o_hs;
+    int B, H, Lq, Lk;
+    int k_len;          // keys >= k_len are masked (k_len <= Lk); 0 -> Lk
+    float scale;        // 1/sqrt(D)
+    // optional segmented token axis (Ulysses receive layout [P_src][...][L/P][...]): token t lives at
+    // (t / seg_len) * *_ss + (t % seg_len) * *_ts ; seg_len == 0 -> plain t * *_ts
+    int seg_len;
+    int64_t q_ss, k_ss, v_ss, o_ss;
+};
+int vc_launch_attention(const VcAttnParams& p, hipStream_t stream);
+
+// ---- row kernels --------------------------------------------------------------------------
+// y = LN(x) * (1 + scale[b]) + shift[b]        (mode 0, WT.py:591,603; head WT.py:643)
+// y = LN(x) * w + bias                        (mode 1, norm3, WT.py:548-550)
+int vc_launch_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
+                        const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream);
+
+// in place on a [rows, dim] slice with row stride ld:  x = rmsnorm(x) * w ; optional 3-axis RoPE
+struct VcRopeGrid { int F, H, W; int token_offset; int rows_per_batch; };
+int vc_launch_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps,
+                           const float2* rope_table /*[1024][64] (cos,sin)*/, const VcRopeGrid* grid,
+                           hipStream_t stream);
+
+// ---- small kernels ------------------------------------------------------------------------
+// A[b*Lrows + i, c*4 + p*2 + q] = x[b, c, f, 2h+p, 2w+q] for token tok = tok_offset + i = (f, h, w)
+// (rows with tok >= F*H2*W2 are zero).  Lrows / tok_offset select a rank's sequence chunk (VC.py:366-367).
+int vc_launch_patchify(const void* x, void* A, int B, int C, int T, int H, int W, int Lrows, int tok_offset,
+                       hipStream_t s);
+// out[b, c, f, 2h+q, 2w+r] = y[row(b, tok), (q*2+r)*C + c],  row = (tok / Lloc) * B * Lloc + b * Lloc + tok % Lloc
+// (the [P][B][Lloc] row order a flat all-gather of per-rank [B, Lloc, 4C] buffers produces; P = 1: b*Lloc + tok)
+int vc_launch_unpatchify(const void* y, void* out, int B, int C, int T, int H2, int W2, int Lloc, hipStream_t s);
+// fp32 "small-M" linear: y[b, n] = act_in(x[b, :]) . W[n, :] + bias[n];  W,bias bf16; x,y fp32
+int vc_launch_small_linear(const float* x, const void* W, const void* bias, float* y, int B, int N, int K,
+                           int silu_input, hipStream_t s);
+// sinusoidal_embedding_1d(freq_dim, t) -> fp32 [B, freq_dim]   (WT.py:39-49)
+int vc_launch_sinusoid(const float* t, float* out, int B, int freq_dim, hipStream_t s);
+// out_bf16[b, j, :] = bf16(mod[j, :] + bf16(e[b*e_bstride + j*e_jstride + :]))   (WT.py:588 / 641; e_jstride 0 = broadcast)
+int vc_launch_modulation(const void* mod, const float* e, void* out, int B, int J, int dim, int64_t e_bstride,
+                         int64_t e_jstride, hipStream_t s);
+// elementwise bf16: out = a + b * s ; out = a - b
+int vc_launch_axpy(const void* a, const void* b, void* out, float s, int64_t n, hipStream_t st);
+int vc_launch_sub(const void* a, const void* b, void* out, int64_t n, hipStream_t st);
+// zero-pad text rows: dst[b, i, :] = i < len[b] ? src_b[i, :] : 0      (VC.py:358-363)
+int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, hipStream_t st);
+// all-to-all pack/unpack for Ulysses (see engine.cpp)
+int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
+                           hipStream_t st);

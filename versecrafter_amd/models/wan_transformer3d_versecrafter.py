@@ -1,0 +1,446 @@
+"""Host-side mirror of the reference's VerseCrafterWanTransformer3DModel, backed by libvcengine.
+
+Same constructor arguments, attributes, state-dict keys and forward signature as
+versecrafter/models/wan_transformer3d_versecrafter.py:151-442 (and the parts of its base class
+versecrafter/models/wan_transformer3d.py:663-1322 that the sampler and the CLI touch), so that
+`WanVerseCrafterPipeline` and `inference/versecrafter_inference.py` can use it unchanged.  The module holds
+parameters only; every FLOP of forward() runs in the HIP engine through the C ABI (include/vcengine.h).
+There is no torch/CPU implementation of forward here: without the HIP library forward() raises.
+"""
+import ctypes as C
+import glob
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..utils.teacache import TeaCache
+
+
+def rope_params(max_seq_len: int, dim: int, theta: float = 10000.0) -> torch.Tensor:
+    """cis table exp(i p theta^(-2j/dim)), complex128 [max_seq_len, dim/2]  (reference: WT.py:52-60)."""
+    inv = 1.0 / torch.pow(torch.tensor(theta, dtype=torch.float64),
+                          torch.arange(0, dim, 2, dtype=torch.float64) / dim)
+    ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), inv)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def rope_params_riflex(max_seq_len: int, dim: int, k: int, L_test: int, L_test_scale=None,
+                       theta: float = 10000.0) -> torch.Tensor:
+    """RIFLEx temporal table (reference: WT.py:63-121): frequency k-1 becomes 0.9*2pi/L_test (/scale)."""
+    inv = 1.0 / torch.pow(torch.tensor(theta, dtype=torch.float64),
+                          torch.arange(0, dim, 2, dtype=torch.float64) / dim)
+    if k is not None:
+        inv[k - 1] = 0.9 * 2 * math.pi / L_test
+    if L_test_scale is not None:
+        inv[k - 1] = inv[k - 1] / L_test_scale
+    ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), inv)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def state_dict_shapes(cfg) -> Dict[str, tuple]:
+    """Key -> shape of the reference state dict."""
+    d, f = cfg.dim, cfg.ffn_dim
+    s = {
+        "patch_embedding.weight": (d, cfg.in_dim, 1, 2, 2), "patch_embedding.bias": (d,),
+        "text_embedding.0.weight": (d, cfg.text_dim), "text_embedding.0.bias": (d,),
+        "text_embedding.2.weight": (d, d), "text_embedding.2.bias": (d,),
+        "time_embedding.0.weight": (d, cfg.freq_dim), "time_embedding.0.bias": (d,),
+        "time_embedding.2.weight": (d, d), "time_embedding.2.bias": (d,),
+        "time_projection.1.weight": (6 * d, d), "time_projection.1.bias": (6 * d,),
+    }
+
+    def block(p):
+        s[p + "modulation"] = (1, 6, d)
+        for a in ("self_attn", "cross_attn"):
+            for l in "qkvo":
+                s[f"{p}{a}.{l}.weight"] = (d, d)
+                s[f"{p}{a}.{l}.bias"] = (d,)
+            s[f"{p}{a}.norm_q.weight"] = (d,)
+            s[f"{p}{a}.norm_k.weight"] = (d,)
+        s[p + "norm3.weight"] = (d,)
+        s[p + "norm3.bias"] = (d,)
+        s[p + "ffn.0.weight"] = (f, d)
+        s[p + "ffn.0.bias"] = (f,)
+        s[p + "ffn.2.weight"] = (d, f)
+        s[p + "ffn.2.bias"] = (d,)
+
+    for i in range(cfg.num_layers):
+        block(f"blocks.{i}.")
+    s["head.head.weight"] = (cfg.out_dim * 4, d)
+    s["head.head.bias"] = (cfg.out_dim * 4,)
+    s["head.modulation"] = (1, 2, d)
+    for n in range(len(cfg.geoada_layers)):
+        p = f"geoada_blocks.{n}."
+        block(p)
+        if n == 0:
+            s[p + "before_proj.weight"] = (d, d)
+            s[p + "before_proj.bias"] = (d,)
+        s[p + "after_proj.weight"] = (d, d)
+        s[p + "after_proj.bias"] = (d,)
+    s["geoada_patch_embedding.weight"] = (d, cfg.geoada_in_dim, 1, 2, 2)
+    s["geoada_patch_embedding.bias"] = (d,)
+    return s
+
+
+class _ParamTree(nn.Module):
+    """Parameter-only container that reproduces a dotted state-dict namespace.  Numeric path components
+    become ModuleList entries, so `model.blocks[i].self_attn.q.weight` resolves as in the reference."""
+
+    def __init__(self):
+        super().__init__()
+
+    def _insert(self, parts: Sequence[str], param: nn.Parameter):
+        head, rest = parts[0], parts[1:]
+        if not rest:
+            self.register_parameter(head, param)
+            return
+        if rest[0].isdigit():
+            if head not in self._modules:
+                self.add_module(head, nn.ModuleList())
+            lst = self._modules[head]
+            idx = int(rest[0])
+            while len(lst) <= idx:
+                lst.append(_ParamTree())
+            lst[idx]._insert(rest[1:], param)
+        else:
+            if head not in self._modules:
+                self.add_module(head, _ParamTree())
+            self._modules[head]._insert(rest, param)
+
+
+def _fingerprint(t: torch.Tensor):
+    """Cheap content key of a step-invariant input (control maps / prompt embeddings)."""
+    v = t.detach().contiguous().view(torch.int16)
+    s1 = v.sum(dtype=torch.int64)
+    s2 = v[1::2].sum(dtype=torch.int64) - 3 * v[::3].sum(dtype=torch.int64)
+    return (tuple(t.shape), t.dtype, t.device, int(s1.item()), int(s2.item()))
+
+
+class VerseCrafterWanTransformer3DModel(_ParamTree):
+    """Drop-in for the reference class of the same name (VC.py:151).  Parameters live in torch; forward()
+    is one call into the HIP engine."""
+
+    def __init__(self, geoada_layers=None, geoada_in_dim=None, model_type="t2v", patch_size=(1, 2, 2), text_len=512,
+                 in_dim=16, dim=2048, ffn_dim=8192, freq_dim=256, text_dim=4096, out_dim=16, num_heads=16,
+                 num_layers=32, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6, **unused):
+        super().__init__()
+        if tuple(patch_size) != (1, 2, 2):
+            raise ValueError("only patch_size (1, 2, 2) is implemented (the reference's fixed value)")
+        if tuple(window_size) != (-1, -1) or not qk_norm or not cross_attn_norm:
+            raise ValueError("engine implements window_size=(-1,-1), qk_norm=True, cross_attn_norm=True "
+                             "(the values VerseCrafter uses)")
+        self.model_type = "t2v"                                                   # VC.py:171
+        self.patch_size, self.text_len, self.in_dim, self.dim = tuple(patch_size), text_len, in_dim, dim
+        self.ffn_dim, self.freq_dim, self.text_dim, self.out_dim = ffn_dim, freq_dim, text_dim, out_dim
+        self.num_heads, self.num_layers, self.window_size = num_heads, num_layers, tuple(window_size)
+        self.qk_norm, self.cross_attn_norm, self.eps = qk_norm, cross_attn_norm, eps
+        self.geoada_layers = list(range(0, num_layers, 2)) if geoada_layers is None else list(geoada_layers)
+        self.geoada_in_dim = in_dim if geoada_in_dim is None else geoada_in_dim
+        assert 0 in self.geoada_layers                                             # VC.py:178
+        self.geoada_layers_mapping = {i: n for n, i in enumerate(self.geoada_layers)}
+        assert dim % num_heads == 0 and (dim // num_heads) % 2 == 0
+        self.d = dim // num_heads
+        self.config = SimpleNamespace(
+            geoada_layers=geoada_layers, geoada_in_dim=geoada_in_dim, model_type=model_type, patch_size=self.patch_size,
+            text_len=text_len, in_dim=in_dim, dim=dim, ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim,
+            out_dim=out_dim, num_heads=num_heads, num_layers=num_layers, window_size=self.window_size,
+            qk_norm=qk_norm, cross_attn_norm=cross_attn_norm, eps=eps)
+
+        for key, shape in state_dict_shapes(self).items():
+            self._insert(key.split("."), nn.Parameter(torch.empty(shape), requires_grad=False))
+        self.freqs = torch.cat([rope_params(1024, self.d - 4 * (self.d // 6)),
+                                rope_params(1024, 2 * (self.d // 6)),
+                                rope_params(1024, 2 * (self.d // 6))], dim=1)      # WT.py:788-795
+
+        self.teacache = None
+        self.cfg_skip_ratio = None
+        self.current_steps = 0
+        self.num_inference_steps = None
+        self.gradient_checkpointing = False
+        self.sp_world_size = 1
+        self.sp_world_rank = 0
+        self.should_calc = True
+        self._sp = None
+        self._engine = None
+        self._loaded = {}           # key -> (data_ptr, version)
+        self._rope_dirty = True
+        self._video_key = None
+        self._sp_dirty = False
+        self.init_weights()
+
+    # ------------------------------------------------------------------ weights
+    def init_weights(self):
+        """Same families as WT.py:1152-1174 / VC.py:106-110 (Xavier linears, zero biases, N(0, .02) embeddings,
+        zero head / before_proj / after_proj, ones for norms)."""
+        for name, p in self.named_parameters():
+            leaf = name.split(".")[-1]
+            if name.endswith("modulation"):
+                p.data = torch.randn_like(p) / self.dim ** 0.5
+            elif "norm" in name and leaf == "weight":
+                nn.init.ones_(p)
+            elif leaf == "bias":
+                nn.init.zeros_(p)
+            elif name.startswith(("text_embedding", "time_embedding")):
+                nn.init.normal_(p, std=.02)
+            elif name == "head.head.weight" or "before_proj" in name or "after_proj" in name:
+                nn.init.zeros_(p)
+            else:
+                nn.init.xavier_uniform_(p.flatten(1) if p.dim() > 2 else p)
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        import inspect
+        params = inspect.signature(cls.__init__).parameters
+        kw = {k: v for k, v in dict(config).items() if k in params}
+        kw.update({k: v for k, v in kwargs.items() if k in params})
+        return cls(**kw)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
+                        low_cpu_mem_usage=False, torch_dtype=torch.bfloat16):
+        """config.json + diffusion_pytorch_model.safetensors | *.safetensors (WT.py:1176-1322, VC.py:203-252).
+        Keys whose shape does not match are skipped, a narrower patch_embedding is zero-padded, and
+        geoada_patch_embedding is Xavier re-initialised when geoada_in_dim differs from the checkpoint's."""
+        from safetensors.torch import load_file
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, "config.json")
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file) as f:
+            config = json.load(f)
+        extra = dict(transformer_additional_kwargs)
+        for k, v in dict(extra.get("dict_mapping", {})).items():                  # WT.py:1195-1197
+            extra[v] = config[k]
+        pre_gd = config.get("geoada_in_dim", config.get("in_dim", 16))
+        req_gd = extra.get("geoada_in_dim", pre_gd)
+        model = cls.from_config(config, **extra)
+        single = os.path.join(pretrained_model_path, "diffusion_pytorch_model.safetensors")
+        files = [single] if os.path.exists(single) else sorted(
+            glob.glob(os.path.join(pretrained_model_path, "*.safetensors")))
+        if not files:
+            raise RuntimeError(f"no .safetensors under {pretrained_model_path} "
+                               "(pickle .bin checkpoints are not loaded by this implementation)")
+        state = {}
+        for fn in files:
+            state.update(load_file(fn))
+        own = model.state_dict()
+        pw = "patch_embedding.weight"
+        if pw in state and own[pw].shape != state[pw].shape:                      # WT.py:1294-1300
+            grown = torch.zeros_like(own[pw])
+            n = min(grown.shape[1], state[pw].shape[1])
+            grown[:, :n] = state[pw][:, :n]
+            state[pw] = grown
+        keep = {}
+        for k, v in state.items():
+            if k in own and own[k].shape == v.shape:
+                keep[k] = v
+            else:
+                print(k, "Size don't match, skip")
+        missing, unexpected = model.load_state_dict(keep, strict=False)
+        print(f"### missing keys: {len(missing)}; \n### unexpected keys: {len(unexpected)};")
+        if req_gd != pre_gd:                                                      # VC.py:242-250
+            w = model.geoada_patch_embedding.weight
+            nn.init.xavier_uniform_(w.data.flatten(1))
+            nn.init.zeros_(model.geoada_patch_embedding.bias.data)
+        return model.to(torch_dtype)
+
+    # ------------------------------------------------------------------ reference API surface
+    def enable_teacache(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0,
+                        offload: bool = True):
+        self.teacache = TeaCache(coefficients, num_steps, rel_l1_thresh=rel_l1_thresh,
+                                 num_skip_start_steps=num_skip_start_steps, offload=offload)
+
+    def share_teacache(self, transformer=None):
+        self.teacache = transformer.teacache
+
+    def disable_teacache(self):
+        self.teacache = None
+
+    def enable_cfg_skip(self, cfg_skip_ratio, num_steps):
+        if cfg_skip_ratio != 0:
+            self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = cfg_skip_ratio, 0, num_steps
+        else:
+            self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    def disable_cfg_skip(self):
+        self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    def enable_riflex(self, k=6, L_test=66, L_test_scale=4.886):
+        self.freqs = torch.cat([rope_params_riflex(1024, self.d - 4 * (self.d // 6), k, L_test, L_test_scale),
+                                rope_params(1024, 2 * (self.d // 6)), rope_params(1024, 2 * (self.d // 6))], dim=1)
+        self._rope_dirty = True
+
+    def disable_riflex(self):
+        self.freqs = torch.cat([rope_params(1024, self.d - 4 * (self.d // 6)), rope_params(1024, 2 * (self.d // 6)),
+                                rope_params(1024, 2 * (self.d // 6))], dim=1)
+        self._rope_dirty = True
+
+    def enable_multi_gpus_inference(self, sp_group=None):
+        """WT.py:901-921: switch self-attention of blocks and geoada_blocks to the Ulysses exchange."""
+        from .. import dist as vdist
+        self._sp = vdist.SequenceParallel(sp_group)
+        self.sp_world_size = self._sp.world_size
+        self.sp_world_rank = self._sp.rank
+        self.all_gather = self._sp.all_gather_dim1
+        self._sp_dirty = True
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine_handle(self):
+        if self._engine is None:
+            lib = _lib.load()
+            cfg = _lib.vc_config()
+            cfg.dim, cfg.ffn_dim, cfg.num_heads, cfg.num_layers = self.dim, self.ffn_dim, self.num_heads, self.num_layers
+            cfg.in_dim, cfg.out_dim, cfg.geoada_in_dim = self.in_dim, self.out_dim, self.geoada_in_dim
+            cfg.text_dim, cfg.text_len, cfg.freq_dim, cfg.eps = self.text_dim, self.text_len, self.freq_dim, self.eps
+            cfg.num_geoada_layers = len(self.geoada_layers)
+            for i, l in enumerate(self.geoada_layers):
+                cfg.geoada_layers[i] = l
+            h = C.c_void_p()
+            _lib.check(lib.vc_create(C.byref(cfg), C.byref(h)))
+            self._engine = h
+        return self._engine
+
+    def _sync_engine(self, device):
+        lib, h = _lib.load(), self._engine_handle()
+        changed = False
+        for key, p in self.named_parameters():
+            if not p.is_cuda:
+                raise RuntimeError(f"parameter {key} is on {p.device}: move the model to the GPU "
+                                   "(versecrafter_amd has no CPU path)")
+            if p.dtype != torch.bfloat16:
+                raise TypeError(f"parameter {key} is {p.dtype}; the engine computes in bf16 (model.to(torch.bfloat16))")
+            if not p.is_contiguous():
+                p.data = p.data.contiguous()
+            tag = (p.data_ptr(), p._version)
+            if self._loaded.get(key) != tag:
+                shape = (C.c_int64 * p.dim())(*p.shape)
+                _lib.check(lib.vc_load_weight(h, key.encode(), C.c_void_p(p.data_ptr()), 0, p.dim(), shape), h)
+                self._loaded[key] = tag
+                changed = True
+        if self._rope_dirty:
+            tab = torch.view_as_real(self.freqs.to(torch.complex128).cpu()).contiguous()
+            _lib.check(lib.vc_set_rope_table(h, C.cast(tab.data_ptr(), C.POINTER(C.c_double)), tab.shape[0],
+                                             tab.shape[1]), h)
+            self._rope_dirty = False
+        if self._sp_dirty:
+            sp = self._sp
+            _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
+            self._sp_dirty = False
+            changed = True
+        if changed:
+            self._video_key = None
+        return h
+
+    def prepare_video(self, geoada_context, context, seq_len, force=False):
+        """Hoisted step-invariant work (control-map patch embedding, text embedding, cross-attn K/V).
+        Called by forward() whenever the control maps / prompt embeddings change."""
+        lib = _lib.load()
+        if isinstance(geoada_context, (list, tuple)):
+            geoada_context = torch.stack(list(geoada_context))
+        if geoada_context.dtype != torch.bfloat16:
+            raise TypeError("geoada_context must be bfloat16")
+        B, Cg, T, H, W = geoada_context.shape
+        if Cg != self.geoada_in_dim:
+            raise ValueError(f"geoada_context has {Cg} channels, model expects geoada_in_dim={self.geoada_in_dim}")
+        if len(context) != B:
+            raise ValueError("one prompt embedding per sample required")
+        h = self._sync_engine(geoada_context.device)
+        key = (int(seq_len), _fingerprint(geoada_context), tuple(_fingerprint(u) for u in context))
+        if not force and key == self._video_key:
+            return
+        g = geoada_context.contiguous()
+        ctx = [u.to(device=g.device, dtype=torch.bfloat16).contiguous() for u in context]
+        for u in ctx:
+            if u.dim() != 2 or u.shape[1] != self.text_dim or u.shape[0] > self.text_len:
+                raise ValueError(f"prompt embedding of shape {tuple(u.shape)} (text_dim {self.text_dim}, "
+                                 f"text_len {self.text_len})")
+        ptrs = (C.c_void_p * B)(*[u.data_ptr() for u in ctx])
+        lens = (C.c_int32 * B)(*[u.shape[0] for u in ctx])
+        stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.vc_prepare_video(h, C.c_void_p(g.data_ptr()), ptrs, lens, B, T, H, W, int(seq_len), stream), h)
+        self._keepalive = (g, ctx)
+        self._video_key = key
+
+    def time_embedding_e0(self, t: torch.Tensor) -> torch.Tensor:
+        """e0 [B, 6, dim] fp32 as VC.py:347-350 computes it (input of the TeaCache gate)."""
+        lib, h = _lib.load(), self._engine_handle()
+        tf = t.to(dtype=torch.float32).contiguous()
+        out = torch.empty(tf.shape[0], 6, self.dim, dtype=torch.float32, device=tf.device)
+        stream = C.c_void_p(torch.cuda.current_stream(tf.device).cuda_stream)
+        _lib.check(lib.vc_time_embedding(h, C.c_void_p(tf.data_ptr()), tf.shape[0], C.c_void_p(out.data_ptr()), stream), h)
+        return out
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, t, geoada_context, context, seq_len, geoada_context_scale=1.0, clip_fea=None, y=None,
+                cond_flag=True):
+        """VC.py:295-442.  x [B,16,T,h,w] (or list of [16,T,h,w]) bf16, t [B], geoada_context [B,128,T,h,w],
+        context: list of [len<=text_len, text_dim]; returns [B,16,T,h,w] in x.dtype."""
+        if isinstance(x, (list, tuple)):
+            if len({tuple(u.shape) for u in x}) != 1:
+                raise ValueError("engine requires all samples of a batch to share one latent shape")
+            x = torch.stack(list(x))
+        if isinstance(geoada_context, (list, tuple)):
+            geoada_context = torch.stack(list(geoada_context))
+        if not x.is_cuda:
+            raise RuntimeError("versecrafter_amd runs on the GPU only (no CPU path): move inputs to cuda")
+        if x.dtype != torch.bfloat16:
+            raise TypeError(f"x must be bfloat16 (weight_dtype of the pipeline), got {x.dtype}")
+        # cfg_skip (third-party decorator, WT.py:850-871): conditional half only for the last `ratio` of steps
+        bs = x.shape[0]
+        skip_uncond = (bs >= 2 and self.cfg_skip_ratio is not None and self.num_inference_steps is not None and
+                       self.current_steps >= self.num_inference_steps * (1 - self.cfg_skip_ratio))
+        if skip_uncond:
+            half = bs // 2
+            x, t, geoada_context, context = x[half:], t[half:], geoada_context[half:], list(context)[half:]
+        B, Cin, T, H, W = x.shape
+        if Cin != self.in_dim or tuple(geoada_context.shape[2:]) != (T, H, W) or geoada_context.shape[0] != B:
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)} geoada_context {tuple(geoada_context.shape)}")
+        lib = _lib.load()
+        self.prepare_video(geoada_context, context, seq_len)
+        h = self._engine
+        tf = t.to(device=x.device, dtype=torch.float32).contiguous()
+        if tf.dim() != 1 or tf.shape[0] != B:
+            raise ValueError("t must have shape [B]")
+
+        flags = _lib.VC_FWD_RUN_MAIN_BLOCKS
+        if self.teacache is not None:                                              # VC.py:384-411
+            if cond_flag:
+                e0 = self.time_embedding_e0(tf).to(torch.bfloat16)               # e0.to(dtype), VC.py:353
+                self.should_calc = self.teacache.gate(e0)
+            if self.should_calc:
+                flags = _lib.VC_FWD_RUN_MAIN_BLOCKS | _lib.VC_FWD_STORE_RESIDUAL
+            else:
+                flags = _lib.VC_FWD_USE_RESIDUAL
+        xc = x.contiguous()
+        out = torch.empty(B, self.out_dim, T, H, W, dtype=torch.bfloat16, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.vc_forward(h, C.c_void_p(xc.data_ptr()), C.c_void_p(tf.data_ptr()),
+                                      C.c_void_p(out.data_ptr()), float(geoada_context_scale), flags, stream), h)
+        if self.teacache is not None and cond_flag:                                # VC.py:438-441
+            self.teacache.cnt += 1
+            if self.teacache.cnt == self.teacache.num_steps:
+                self.teacache.reset()
+        if skip_uncond:
+            out = torch.cat([out, out], dim=0)
+        return out
+
+    def workspace_bytes(self) -> int:
+        return 0 if self._engine is None else int(_lib.load().vc_workspace_bytes(self._engine))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_engine", None) is not None and _lib._lib is not None:
+                _lib._lib.vc_destroy(self._engine)
+                self._engine = None
+        except Exception:
+            pass

@@ -1,0 +1,110 @@
+"""Per-kernel entry points of libvcengine on torch CUDA tensors (used by the parity tests and by tuning
+scripts).  Each function enqueues one HIP kernel on torch's current stream; nothing here computes on the
+host, and every call fails loudly if the tensors are not bf16 CUDA tensors."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID = 0, 1, 2, 3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.bfloat16):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (HIP) tensor: versecrafter_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, rows_per_batch=0, hint=None, hint_scale=0.0,
+         out=None, tile=0):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  gate: [B, N] rows selected by m // rows_per_batch."""
+    lib = _lib.load()
+    _chk(a, "a"); _chk(w, "w"); _chk(bias, "bias"); _chk(resid, "resid"); _chk(gate, "gate"); _chk(hint, "hint")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    rc = lib.vc_op_gemm_bf16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _ptr(bias), M, N, K,
+                             epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate),
+                             0 if gate is None else gate.stride(0), rows_per_batch, _ptr(hint),
+                             0 if hint is None else hint.stride(0), float(hint_scale), tile, _stream())
+    _lib.check(rc)
+    return out
+
+
+def attention(q, k, v, k_len=0, scale=None, out=None):
+    """q [B,Lq,H,128], k/v [B,Lk,H,128] (any strides with a contiguous last dim) -> [B,Lq,H,128]."""
+    lib = _lib.load()
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if out is None:
+        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    st = lambda t: _lib.i64x3(t.stride(0), t.stride(1), t.stride(2))
+    rc = lib.vc_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out),
+                             int(k_len), float(scale), _stream())
+    _lib.check(rc)
+    return out
+
+
+def layernorm_modulate(x, scale, shift, rows_per_batch, eps=1e-6):
+    """y = LN(x) * (1 + scale[b]) + shift[b];  x [rows, dim], scale/shift [B, dim] (same row stride)."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(scale, "scale"); _chk(shift, "shift")
+    assert x.is_contiguous() and scale.stride(0) == shift.stride(0)
+    y = torch.empty_like(x)
+    rc = lib.vc_op_layernorm(_ptr(x), _ptr(y), x.shape[0], x.shape[1], rows_per_batch, eps, 0, _ptr(scale),
+                             _ptr(shift), scale.stride(0), _stream())
+    _lib.check(rc)
+    return y
+
+
+def layernorm_affine(x, weight, bias, eps=1e-6):
+    lib = _lib.load()
+    _chk(x, "x"); _chk(weight, "weight"); _chk(bias, "bias")
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    rc = lib.vc_op_layernorm(_ptr(x), _ptr(y), x.shape[0], x.shape[1], 0, eps, 1, _ptr(weight), _ptr(bias), 0,
+                             _stream())
+    _lib.check(rc)
+    return y
+
+
+def rope_table_device(cis, device):
+    """complex128 [1024, 64] cis table -> float2 (cos, sin) device table the kernels read."""
+    t = torch.view_as_real(cis.to(torch.complex128)).to(torch.float32).contiguous()
+    return t.to(device)
+
+
+def rmsnorm_rope_(x, weight, eps=1e-6, table=None, grid=None, token_offset=0, rows_per_batch=0):
+    """In place on x [rows, dim] (row stride free): WanRMSNorm, then rope_apply when `table` is given.
+    grid = (F, H, W) of the token lattice."""
+    lib = _lib.load()
+    _chk(x, "x"); _chk(weight, "weight")
+    assert x.stride(1) == 1
+    g = None
+    if table is not None:
+        _chk(table, "table", torch.float32)
+        g = (C.c_int32 * 5)(int(grid[0]), int(grid[1]), int(grid[2]), int(token_offset), int(rows_per_batch))
+    rc = lib.vc_op_rmsnorm_rope(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(weight), eps, _ptr(table), g,
+                                _stream())
+    _lib.check(rc)
+    return x
