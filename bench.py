@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the VerseCrafter denoise step on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): denoise-steps/sec, Wan2.1-14B + GeoAdapter, 81 frames x 480p (480x832 -> latent
+[16,21,60,104], 32760 tokens), CFG pair batched (B=2), TeaCache and cfg_skip off -- one "step" is one
+iteration of the reference's sampler loop (pipeline_wan_versecrafter.py:871-925): transformer forward at B=2,
+CFG combine, UniPC scheduler step.  Synthetic inputs and random weights of that architecture; all
+inputs are resident in HBM before the timed region.  For N > 1 the frames x h x w token sequence is sharded
+Ulysses-style over the ranks (one process per GPU, torch.distributed "nccl" = RCCL): total work is fixed, so
+"scaling" is "strong".  Rank 0 prints ONE JSON line.
+
+The same line carries
+  roofline     : the dominant kernel class of the timed region (HIP events around every launch of the class,
+                 on the launch stream) -- algorithmic FLOPs / summed duration vs the dense bf16 MFMA peak;
+  breakdown    : the same for every kernel class, plus the whole-step fraction of the MFMA roofline;
+  cpu_baseline : the CPU oracle (oracle/wan_oracle.py, fp32 PyTorch) timed on this box's host cores on a bounded
+                 sample (one DiT block at the 14B width on a 1536-token slice) and extrapolated by FLOPs.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+WORKLOADS = {
+    # name: (model kwargs, frames, height, width)
+    "wan14b-81f-480x832": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 81, 480, 832),
+    "wan14b-49f-480x832": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 49, 480, 832),
+    "wan1.3b-9f-320x512": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), 9, 320, 512),
+    "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=4, text_dim=64, text_len=48), 9, 64, 96),
+}
+
+
+def step_flops(d, ffn, NL, NA, L, B=2, text_len=512, text_dim=4096):
+    """F_step = B [ (NL+NA) F_blk + (NA+1) 2 L d^2 + F_embed ]."""
+    f_blk = 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + 4 * text_len * d * d + 4 * L * text_len * d + 4 * L * d * ffn
+    f_embed = (2 * L * 64 * d + 2 * L * 512 * d + 2 * text_len * text_dim * d + 2 * text_len * d * d + 2 * L * d * 64 +
+               (2 * 256 * d + 2 * d * d + 12 * d * d))
+    return B * ((NL + NA) * f_blk + (NA + 1) * 2 * L * d * d + f_embed)
+
+
+def cpu_baseline(mk, f_step):
+    """Oracle timed on the host cores on a bounded sample; extrapolated to steps/s by algorithmic FLOPs."""
+    from oracle import wan_oracle as O
+    d, ffn, heads = mk["dim"], mk["ffn_dim"], mk["num_heads"]
+    text_len = mk.get("text_len", 512)
+    Ls = 1536 if d >= 1024 else 256
+    cfg = O.Config(dim=d, ffn_dim=ffn, num_heads=heads, num_layers=1, text_len=text_len, text_dim=mk.get("text_dim", 4096))
+    g = torch.Generator().manual_seed(0)
+    W = {}
+    for k, shp in O.state_dict_shapes(cfg).items():
+        if k.startswith("blocks.0."):
+            W[k] = torch.randn(shp, generator=g) * (0.02 if len(shp) > 1 else 1.0)
+    grid = (3, 16, Ls // 48) if Ls == 1536 else (1, 16, 16)
+    x = torch.randn(1, Ls, d, generator=g)
+    e0 = torch.randn(1, 6, d, generator=g) * 0.1
+    ctx = torch.randn(1, text_len, d, generator=g)
+    freqs = O.rope_table(128)
+    flops = (8 * Ls * d * d + 4 * Ls * Ls * d + 4 * Ls * d * d + 4 * text_len * d * d + 4 * Ls * text_len * d + 4 * Ls * d * ffn)
+    times = []
+    t_end = time.time() + 25.0
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.time()
+            O.attention_block(W, "blocks.0.", x, e0, [Ls], [grid], freqs, ctx, heads)
+            times.append(time.time() - t0)
+            if time.time() > t_end:
+                break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    rate = flops / best
+    return {"value": rate / f_step, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.attention_block fp32, 1 block, B=1, {Ls} tokens, d={d}: {best:.2f} s = "
+                      f"{rate / 1e12:.3f} TFLOP/s, extrapolated by FLOPs to a full step ({f_step / 1e15:.3f} PFLOP)",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wan14b-81f-480x832", choices=sorted(WORKLOADS))
+    ap.add_argument("--num_inference_steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+    mk, frames, height, width = WORKLOADS[args.workload]
+    mk = dict(mk)
+    T, h, w = (frames - 1) // 4 + 1, height // 8, width // 8
+    L = T * (h // 2) * (w // 2)
+    text_dim = mk.get("text_dim", 4096)
+
+    # ---- model: random weights of the named architecture, identical on every rank (seed 0) ----
+    torch.manual_seed(0)
+    model = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16, **mk)
+    model.init_weights(zero_init_outputs=False)
+    if world > 1:
+        from versecrafter_amd import dist as vdist
+        vdist._SP_GROUP = dist.group.WORLD
+        model.enable_multi_gpus_inference()
+    scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    pipe = WanVerseCrafterPipeline(transformer=model, scheduler=scheduler)
+    pipe._guidance_scale = 5.0
+
+    # ---- synthetic inputs, seed 2025, resident in HBM ----
+    g = torch.Generator(device="cpu").manual_seed(2025)
+    latents = torch.randn(1, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    ctrl = torch.randn(1, 64, T, h, w, generator=g)
+    mask = (torch.rand(1, 64, T, h, w, generator=g) < 0.5).float()
+    mask[:, :, 0] = 0
+    geoada = torch.cat([ctrl, mask], 1).to(dev, torch.bfloat16)
+    geoada_in = torch.cat([geoada, geoada], 0).contiguous()
+    n_un, n_co = (60, 77) if mk.get("text_len", 512) >= 77 else (20, 33)
+    embeds = [torch.randn(n_un, text_dim, generator=g).to(dev, torch.bfloat16),    # uncond
+              torch.randn(n_co, text_dim, generator=g).to(dev, torch.bfloat16)]    # cond
+    scheduler.set_timesteps(args.num_inference_steps, device=dev, shift=16)
+    ts = scheduler.timesteps
+    seq_len = L
+
+    def run_steps(lat, first, n):
+        for i in range(first, first + n):
+            lat = pipe.denoise_step(i, ts[i], lat, embeds, geoada_in, seq_len, True, 1.0)
+        return lat
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lat = run_steps(latents, 0, args.warmup)
+    barrier()
+    if not args.no_profile:
+        model.profile_enable(True)
+    t0 = time.perf_counter()
+    lat = run_steps(lat, args.warmup, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = model.profile_read()
+        model.profile_enable(False)
+    finite = bool(torch.isfinite(lat.float()).all().item())
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        NL, NA = mk["num_layers"], (mk["num_layers"] + 1) // 2
+        f_step = step_flops(mk["dim"], mk["ffn_dim"], NL, NA, L, 2, mk.get("text_len", 512), text_dim)
+        sps = args.steps / elapsed
+        out = {
+            "metric": "denoise-steps/sec Wan2.1-14B+GeoAdapter 81fx480p" if args.workload.startswith("wan14b-81f")
+                      else f"denoise-steps/sec {args.workload}",
+            "value": sps, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights seed 0, inputs seed 2025)",
+            "config": {"workload": args.workload, "latent": [16, T, h, w], "tokens": L, "global_batch": 2,
+                       "cfg": "batched pair", "guidance_scale": 5.0, "sampler": "UniPC shift 16",
+                       "teacache": "off", "parallelism": f"ulysses-sp{world}", "pflop_per_step": f_step / 1e15},
+            "step_mfma_frac": f_step * sps / (world * PEAK_BF16_TFLOPS * 1e12),
+            "outputs_finite": finite,
+        }
+        if prof is not None:
+            bd = {}
+            for k, v in prof.items():
+                if v["launches"]:
+                    sec = v["ms"] / 1e3
+                    bd[k] = {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
+                             "avg_ms": v["ms"] / v["launches"], "tflops": v["flops"] / sec / 1e12 if v["flops"] else None,
+                             "gbps": v["bytes"] / sec / 1e9}
+            dom = max(("attn_self", "gemm"), key=lambda k: prof[k]["ms"])
+            v = prof[dom]
+            ach = v["flops"] / (v["ms"] / 1e3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": {"attn_self": "attn_fwd_kernel", "gemm": "gemm_bf16_kernel"}[dom],
+                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
+            out["breakdown"] = bd
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mk, f_step)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

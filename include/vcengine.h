@@ -90,6 +90,18 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
 /* time-embedding only: e0 [B, 6, dim] fp32 (device) for the TeaCache gate (WT.py:205-245), VC.py:347-354 */
 int vc_time_embedding(vc_engine* h, const float* t, int B, float* e0_out, void* stream);
 
+/* Live per-kernel-class timing for bench.py's roofline line: when enabled, every launch of a class inside
+ * vc_forward is bracketed by HIP events on the launch stream.  vc_profile_read synchronises those events and
+ * returns, per class, launch count, summed duration (ms), algorithmic FLOPs (GEMM 2MNK, attention 4 B H Lq Lk D)
+ * and algorithmic bytes, then clears the records. */
+#define VC_PROF_GEMM 0
+#define VC_PROF_ATTN_SELF 1
+#define VC_PROF_ATTN_CROSS 2
+#define VC_PROF_ROW 3       /* LayerNorm / RMSNorm+RoPE row kernels */
+#define VC_PROF_NCLASS 4
+int vc_profile_enable(vc_engine* h, int on);
+int vc_profile_read(vc_engine* h, int ncls, int64_t* count, double* ms, double* flops, double* bytes);
+
 /* bytes of library-owned device workspace currently allocated */
 int64_t vc_workspace_bytes(const vc_engine* h);
 

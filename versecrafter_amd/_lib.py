@@ -43,6 +43,9 @@ SYMBOLS = {
     "vc_forward": (_I, [_P, _P, _P, _P, _F, C.c_uint32, _P]),
     "vc_time_embedding": (_I, [_P, _P, _I, _P, _P]),
     "vc_workspace_bytes": (_L, [_P]),
+    "vc_profile_enable": (_I, [_P, _I]),
+    "vc_profile_read": (_I, [_P, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double)]),
     "vc_op_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _L, _F, _I, _P]),
     "vc_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                              C.POINTER(_L), _I, _F, _P]),

@@ -79,6 +79,12 @@ struct vc_engine {
     float *f_sin, *f_h, *f_e, *f_e0;
     void* small = nullptr;   // fp32 scratch for vc_time_embedding before prepare
 
+    // optional per-kernel-class timing (vc_profile_*): HIP event pairs around every launch of a class
+    bool prof_on = false;
+    struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; };
+    std::vector<ProfRec> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+
     std::string err;
 };
 
@@ -108,6 +114,31 @@ int fail(vc_engine* h, int code, const char* fmt, ...) {
                         _e != hipSuccess ? hipGetErrorString(_e) : "");                                  \
         }                                                                                                \
     } while (0)
+
+struct ProfScope {
+    vc_engine* h; hipStream_t s; int idx = -1;
+    ProfScope(vc_engine* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!h->prof_pool.empty()) { ev = h->prof_pool.back(); h->prof_pool.pop_back(); }
+        else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return;
+        (void)hipEventRecord(ev.first, s);
+        h->prof.push_back({cls, ev.first, ev.second, flops, bytes});
+        idx = (int)h->prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof[idx].b, s); }
+};
+
+int p_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, int cls = VC_PROF_GEMM) {
+    ProfScope ps(h, s, cls, 2.0 * g.M * g.N * (double)g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    return vc_launch_gemm(g, s);
+}
+int p_attn(vc_engine* h, const VcAttnParams& a, hipStream_t s, int cls) {
+    const double kl = (a.k_len > 0 && a.k_len < a.Lk) ? a.k_len : a.Lk;
+    ProfScope ps(h, s, cls, 4.0 * a.B * a.H * (double)a.Lq * kl * 128.0,
+                 2.0 * a.B * a.H * 128.0 * (2.0 * a.Lq + 2.0 * kl));
+    return vc_launch_attention(a, s);
+}
 
 void add_slot(vc_engine* h, const std::string& k, std::vector<int64_t> shape) {
     h->slots[k].shape = std::move(shape);
@@ -217,7 +248,7 @@ int self_attention(vc_engine* h, hipStream_t s) {
         a.q_hs = a.k_hs = a.v_hs = 128;
         a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.H = N; a.Lq = Lloc; a.Lk = Lloc; a.k_len = h->L;
-        VCCHK(h, vc_launch_attention(a, s));
+        VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
         return VC_OK;
     }
     // ---- Ulysses: scatter heads / gather sequence, attend over the full sequence with N/P heads, and back ----
@@ -242,7 +273,7 @@ int self_attention(vc_engine* h, hipStream_t s) {
     // out (send buffer of the return exchange): [P_dst][B][Lloc][Nl][128]
     a.out = h->a2a_send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
-    VCCHK(h, vc_launch_attention(a, s));
+    VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
     if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, blk * 2, (void*)s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (o)");
     // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
@@ -261,20 +292,20 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     // e = modulation + e0  (WT.py:588)
     VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, h->mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
-    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s));
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
     // q, k, v projections into [M, 3d]  (WT.py:385-387)
     {
         VcGemmParams g = gemm(h->tb, d, w.sa_q_w, w.sa_q_b, h->qkv, 3 * d, M, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
         g = gemm(h->tb, d, w.sa_k_w, w.sa_k_b, (char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
         g = gemm(h->tb, d, w.sa_v_w, w.sa_v_b, (char*)h->qkv + (int64_t)2 * d * 2, 3 * d, M, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
-    VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s));
-    VCCHK(h, vc_launch_rmsnorm_rope((char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s));
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
     {
         int r = self_attention(h, s);
         if (r != VC_OK) return r;
@@ -283,15 +314,15 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     {
         VcGemmParams g = gemm(h->attn, d, w.sa_o_w, w.sa_o_b, xs, d, M, d, d, VC_EPI_BIAS_GATE_RESID);
         g.resid = xs; g.ldr = d; g.gate = modp(2); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // cross attention: x = x + o(attn(rms(q(norm3(x))), K, V))  (WT.py:600, 410-436)
-    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s));
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s)); }
     {
         VcGemmParams g = gemm(h->tb, d, w.ca_q_w, w.ca_q_b, h->qkv, d, M, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
-    VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, d, M, d, w.ca_nq, eps, nullptr, nullptr, s));
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, d, M, d, w.ca_nq, eps, nullptr, nullptr, s)); }
     {
         VcAttnParams a;
         memset(&a, 0, sizeof a);
@@ -301,20 +332,20 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
         a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
-        VCCHK(h, vc_launch_attention(a, s));
+        VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_CROSS));
         VcGemmParams g = gemm(h->attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
         g.resid = xs; g.ldr = d;
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // ffn: x = x + ffn(norm2(x) * (1 + e4) + e3) * e5  (WT.py:603-607)  [+ hint * scale, VC.py:147]
-    VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s));
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s)); }
     {
         VcGemmParams g = gemm(h->tb, d, w.f0_w, w.f0_b, h->hb, f, M, f, d, VC_EPI_BIAS_GELU);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
         g = gemm(h->hb, f, w.f2_w, w.f2_b, xs, d, M, d, f, VC_EPI_BIAS_GATE_RESID);
         g.resid = xs; g.ldr = d; g.gate = modp(5); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
         g.hint = hint; g.ldh = d; g.hint_scale = hint_scale;
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     return VC_OK;
 }
@@ -526,7 +557,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         VcGemmParams g = gemm(h->patchA, c.geoada_in_dim * 4, h->gpe_w, h->gpe_b, h->c0, d, M, d, c.geoada_in_dim * 4);
         g.rows_per_batch = Lloc;
         int vr = L - h->tok_off; g.valid_rows = vr < 0 ? 0 : (vr > Lloc ? Lloc : vr);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // ---- text embedding (VC.py:358-363) ----
     for (int i = 0; i < B; ++i)
@@ -535,18 +566,18 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     {
         VcGemmParams g = gemm(h->ctxpad, c.text_dim, h->te0_w, h->te0_b, h->ctxh, d, B * TL, d, c.text_dim,
                               VC_EPI_BIAS_GELU);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
         g = gemm(h->ctxh, d, h->te2_w, h->te2_b, h->ctx, d, B * TL, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // ---- cross-attention k / v of every block (WT.py:421-422) ----
     for (int i = 0; i < nblk; ++i) {
         BlockW& bw = i < c.num_layers ? h->blocks[i] : h->gblocks[i - c.num_layers];
         VcGemmParams g = gemm(h->ctx, d, bw.ca_k_w, bw.ca_k_b, bw.ck, d, B * TL, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
         VCCHK(h, vc_launch_rmsnorm_rope(bw.ck, d, B * TL, d, bw.ca_nk, c.eps, nullptr, nullptr, s));
         g = gemm(h->ctx, d, bw.ca_v_w, bw.ca_v_b, bw.cv, d, B * TL, d, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     h->prepared = true;
     return VC_OK;
@@ -581,7 +612,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         VcGemmParams g = gemm(h->patchA, c.in_dim * 4, h->pe_w, h->pe_b, h->x, d, M, d, c.in_dim * 4);
         g.rows_per_batch = Lloc;
         int vr = h->L - h->tok_off; g.valid_rows = vr < 0 ? 0 : (vr > Lloc ? Lloc : vr);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     // ---- time embeddings (VC.py:347-354) ----
     { int r = time_embed(h, t, B, h->f_sin, h->f_h, h->f_e, h->f_e0, s); if (r != VC_OK) return r; }
@@ -593,7 +624,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             const BlockW& g0 = h->gblocks[0];
             VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
             g.resid = h->x; g.ldr = d;
-            VCCHK(h, vc_launch_gemm(g, s));
+            VCCHK(h, p_gemm(h, g, s));
         }
         size_t next_adapter = 0;
         for (int i = 0; i < c.num_layers; ++i) {
@@ -604,7 +635,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                     int r = run_block(h, gb, h->c, nullptr, 0.f, s);
                     if (r != VC_OK) return r;
                     VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint, d, M, d, d);
-                    VCCHK(h, vc_launch_gemm(g, s));
+                    VCCHK(h, p_gemm(h, g, s));
                     ++next_adapter;
                 }
             }
@@ -625,7 +656,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                                  2 * d, s));
     {
         VcGemmParams g = gemm(h->tb, d, h->head_w, h->head_b, h->ybuf, c.out_dim * 4, M, c.out_dim * 4, d);
-        VCCHK(h, vc_launch_gemm(g, s));
+        VCCHK(h, p_gemm(h, g, s));
     }
     const void* y = h->ybuf;
     if (h->P > 1) {                                          // VC.py:432-433
@@ -634,6 +665,26 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         y = h->yfull;
     }
     VCCHK(h, vc_launch_unpatchify(y, out, B, c.out_dim, h->T, h->H2, h->W2, Lloc, s));
+    return VC_OK;
+}
+
+int vc_profile_enable(vc_engine* h, int on) {
+    if (!h) return VC_E_INVALID;
+    h->prof_on = on != 0;
+    return VC_OK;
+}
+
+int vc_profile_read(vc_engine* h, int ncls, int64_t* count, double* ms, double* flops, double* bytes) {
+    if (!h || !count || !ms || !flops || !bytes || ncls < VC_PROF_NCLASS) return fail(h, VC_E_INVALID, "vc_profile_read: bad argument");
+    for (int i = 0; i < ncls; ++i) { count[i] = 0; ms[i] = flops[i] = bytes[i] = 0; }
+    for (auto& r : h->prof) {
+        HIPCHK(h, hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, r.a, r.b));
+        count[r.cls] += 1; ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes;
+        h->prof_pool.push_back({r.a, r.b});
+    }
+    h->prof.clear();
     return VC_OK;
 }
 

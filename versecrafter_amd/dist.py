@@ -1,0 +1,171 @@
+"""Sequence parallelism (Ulysses) plumbing over torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Stands in for the parts of the un-vendored videox_fun.dist that the reference's hot path uses
+(wan_transformer3d.py:30-32, 901-921; wan_transformer3d_versecrafter.py:269-270, 366-367, 432-433;
+inference/versecrafter_inference.py:180): group set-up, rank / world size, the head-scatter
+all-to-all around self-attention and the final all-gather.  The HIP engine packs / unpacks the exchange
+buffers itself and calls back into this module only for the collective (include/vcengine.h: vc_sp_init).
+
+Layout contract of one exchange (P ranks, B samples, Lloc = L/P local tokens, Nl = N/P local heads):
+    send  [P_dst][3 (q,k,v)][B][Lloc][Nl][128]  --all_to_all-->  recv [P_src][3][B][Lloc][Nl][128]
+    attention over the full sequence (token t = src * Lloc + i) with Nl heads writes
+    send  [P_dst (token owner)][B][Lloc][Nl][128] --all_to_all--> recv [P_src (head group)][B][Lloc][Nl][128]
+`pack_qkv` / `unpack_tokens` / `pack_out` / `unpack_heads` below restate that contract on torch tensors; the
+multi-process CPU tests (gloo) drive them together with the byte-level collectives the engine uses.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_SP_GROUP = None
+
+
+def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int):
+    """CLI.py:180.  One process per GPU (torchrun env); returns this rank's device.  The reference's
+    ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring (head counts divide)."""
+    global _SP_GROUP
+    degree = int(ulysses_degree) * int(ring_degree)
+    if degree > 1:
+        if not dist.is_initialized():
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            dist.init_process_group(backend)
+        if dist.get_world_size() != degree:
+            raise ValueError(f"ulysses_degree*ring_degree = {degree} but world size is {dist.get_world_size()}")
+        if int(ring_degree) > 1 and dist.get_rank() == 0:
+            print(f"[versecrafter_amd] ring_degree={ring_degree} folded into a pure Ulysses degree of {degree}")
+        _SP_GROUP = dist.group.WORLD
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+    return torch.device("cpu")
+
+
+def get_sp_group():
+    return _SP_GROUP
+
+
+def get_sequence_parallel_world_size():
+    return 1 if _SP_GROUP is None else dist.get_world_size(_SP_GROUP)
+
+
+def get_sequence_parallel_rank():
+    return 0 if _SP_GROUP is None else dist.get_rank(_SP_GROUP)
+
+
+# ---- byte-level collectives (device-agnostic torch plumbing) --------------------------------------
+def all_to_all_bytes(send: torch.Tensor, recv: torch.Tensor, group=None):
+    """send / recv: flat uint8 tensors of P equal slices; slice r of `send` goes to rank r."""
+    dist.all_to_all_single(recv, send, group=group)
+
+
+def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None):
+    """recv (P * len(send)) = concatenation over ranks of `send`."""
+    dist.all_gather_into_tensor(recv, send, group=group)
+
+
+# ---- the exchange-buffer layout contract, on tensors ----------------------------------------------
+def pack_qkv(qkv: torch.Tensor, P: int) -> torch.Tensor:
+    """qkv [B, Lloc, 3, N, D] -> send [P, 3, B, Lloc, N/P, D]."""
+    B, Lloc, three, N, D = qkv.shape
+    return qkv.view(B, Lloc, 3, P, N // P, D).permute(3, 2, 0, 1, 4, 5).contiguous()
+
+
+def unpack_tokens(recv: torch.Tensor):
+    """recv [P_src, 3, B, Lloc, Nl, D] -> q, k, v each [B, P*Lloc, Nl, D] (token t = src*Lloc + i)."""
+    P, three, B, Lloc, Nl, D = recv.shape
+    full = recv.permute(1, 2, 0, 3, 4, 5).reshape(3, B, P * Lloc, Nl, D)
+    return full[0], full[1], full[2]
+
+
+def pack_out(o: torch.Tensor, P: int) -> torch.Tensor:
+    """o [B, P*Lloc, Nl, D] -> send [P_dst, B, Lloc, Nl, D]."""
+    B, L, Nl, D = o.shape
+    return o.view(B, P, L // P, Nl, D).permute(1, 0, 2, 3, 4).contiguous()
+
+
+def unpack_heads(recv: torch.Tensor) -> torch.Tensor:
+    """recv [P_src, B, Lloc, Nl, D] -> [B, Lloc, P*Nl, D] (head = src*Nl + hl)."""
+    P, B, Lloc, Nl, D = recv.shape
+    return recv.permute(1, 2, 0, 3, 4).reshape(B, Lloc, P * Nl, D)
+
+
+def ulysses_attention(q, k, v, attn_fn, group=None):
+    """Reference semantics of usp_attn_forward's exchange (third-party) on local
+    [B, Lloc, N, D] tensors: returns the local [B, Lloc, N, D] attention output."""
+    P = dist.get_world_size(group)
+    B, Lloc, N, D = q.shape
+    send = pack_qkv(torch.stack([q, k, v], dim=2), P)
+    recv = torch.empty_like(send)
+    all_to_all_bytes(send.view(torch.uint8).flatten(), recv.view(torch.uint8).flatten(), group)
+    qf, kf, vf = unpack_tokens(recv)
+    o = attn_fn(qf, kf, vf)
+    send2 = pack_out(o.contiguous(), P)
+    recv2 = torch.empty_like(send2)
+    all_to_all_bytes(send2.view(torch.uint8).flatten(), recv2.view(torch.uint8).flatten(), group)
+    return unpack_heads(recv2)
+
+
+class _DevBuf:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it (no copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def alias_device_bytes(ptr: int, nbytes: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevBuf(ptr, nbytes), device=device)
+
+
+class SequenceParallel:
+    """Owns the callbacks handed to vc_sp_init.  The engine calls them from inside vc_forward with raw
+    pointers into its workspace; they are aliased as uint8 torch tensors and exchanged with
+    torch.distributed on the caller's current stream."""
+
+    def __init__(self, group=None):
+        self.group = group if group is not None else get_sp_group()
+        if self.group is None and dist.is_initialized():
+            self.group = dist.group.WORLD
+        self.world_size = 1 if self.group is None else dist.get_world_size(self.group)
+        self.rank = 0 if self.group is None else dist.get_rank(self.group)
+        self.error = None
+        self._alias = {}
+        self.c_all_to_all = _lib.ALL_TO_ALL_FN(self._a2a)
+        self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
+
+    def _buf(self, ptr, nbytes):
+        key = (ptr, nbytes)
+        t = self._alias.get(key)
+        if t is None:
+            t = alias_device_bytes(ptr, nbytes, torch.device("cuda", torch.cuda.current_device()))
+            self._alias[key] = t
+        return t
+
+    def _a2a(self, ctx, send, recv, bytes_per_peer, stream):
+        try:
+            n = bytes_per_peer * self.world_size
+            all_to_all_bytes(self._buf(send, n), self._buf(recv, n), self.group)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            self.error = e
+            return -1
+
+    def _ag(self, ctx, send, recv, nbytes, stream):
+        try:
+            all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self.group)
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1
+
+    def all_gather_dim1(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
+        """get_sp_group().all_gather(x, dim=1) of the reference (VC.py:432-433)."""
+        if self.world_size == 1:
+            return x
+        parts = [torch.empty_like(x) for _ in range(self.world_size)]
+        dist.all_gather(parts, x.contiguous(), group=self.group)
+        return torch.cat(parts, dim=dim)

@@ -128,7 +128,10 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
 
     def __init__(self, geoada_layers=None, geoada_in_dim=None, model_type="t2v", patch_size=(1, 2, 2), text_len=512,
                  in_dim=16, dim=2048, ffn_dim=8192, freq_dim=256, text_dim=4096, out_dim=16, num_heads=16,
-                 num_layers=32, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6, **unused):
+                 num_layers=32, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6,
+                 param_device=None, param_dtype=None, **unused):
+        """`param_device` / `param_dtype` (extensions): allocate the parameters directly there, e.g.
+        ("cuda", torch.bfloat16) for the 14B model whose fp32 host copy would not fit in RAM."""
         super().__init__()
         if tuple(patch_size) != (1, 2, 2):
             raise ValueError("only patch_size (1, 2, 2) is implemented (the reference's fixed value)")
@@ -153,7 +156,8 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             qk_norm=qk_norm, cross_attn_norm=cross_attn_norm, eps=eps)
 
         for key, shape in state_dict_shapes(self).items():
-            self._insert(key.split("."), nn.Parameter(torch.empty(shape), requires_grad=False))
+            self._insert(key.split("."), nn.Parameter(torch.empty(shape, device=param_device, dtype=param_dtype),
+                                                      requires_grad=False))
         self.freqs = torch.cat([rope_params(1024, self.d - 4 * (self.d // 6)),
                                 rope_params(1024, 2 * (self.d // 6)),
                                 rope_params(1024, 2 * (self.d // 6))], dim=1)      # WT.py:788-795
@@ -175,9 +179,10 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         self.init_weights()
 
     # ------------------------------------------------------------------ weights
-    def init_weights(self):
+    def init_weights(self, zero_init_outputs: bool = True):
         """Same families as WT.py:1152-1174 / VC.py:106-110 (Xavier linears, zero biases, N(0, .02) embeddings,
-        zero head / before_proj / after_proj, ones for norms)."""
+        zero head / before_proj / after_proj, ones for norms).  zero_init_outputs=False gives the synthetic
+        benchmark weights of SURVEY 8d (those three also Xavier, else every output is identically 0)."""
         for name, p in self.named_parameters():
             leaf = name.split(".")[-1]
             if name.endswith("modulation"):
@@ -188,7 +193,7 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
                 nn.init.zeros_(p)
             elif name.startswith(("text_embedding", "time_embedding")):
                 nn.init.normal_(p, std=.02)
-            elif name == "head.head.weight" or "before_proj" in name or "after_proj" in name:
+            elif zero_init_outputs and (name == "head.head.weight" or "before_proj" in name or "after_proj" in name):
                 nn.init.zeros_(p)
             else:
                 nn.init.xavier_uniform_(p.flatten(1) if p.dim() > 2 else p)
@@ -433,6 +438,20 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         if skip_uncond:
             out = torch.cat([out, out], dim=0)
         return out
+
+    # ------------------------------------------------------------------ live kernel timing (bench.py)
+    PROF_CLASSES = ("gemm", "attn_self", "attn_cross", "row")
+
+    def profile_enable(self, on: bool = True):
+        _lib.check(_lib.load().vc_profile_enable(self._engine_handle(), int(on)), self._engine)
+
+    def profile_read(self) -> Dict[str, dict]:
+        """Per kernel class: launches, summed HIP-event duration (ms), algorithmic FLOPs and bytes."""
+        n = len(self.PROF_CLASSES)
+        cnt, ms, fl, by = (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        _lib.check(_lib.load().vc_profile_read(self._engine_handle(), n, cnt, ms, fl, by), self._engine)
+        return {k: dict(launches=int(cnt[i]), ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i]))
+                for i, k in enumerate(self.PROF_CLASSES)}
 
     def workspace_bytes(self) -> int:
         return 0 if self._engine is None else int(_lib.load().vc_workspace_bytes(self._engine))

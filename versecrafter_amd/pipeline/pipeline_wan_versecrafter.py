@@ -1,0 +1,218 @@
+"""Sampler: host-side mirror of the reference's WanVerseCrafterPipeline
+(versecrafter/pipeline/pipeline_wan_versecrafter.py:170-948) around the HIP denoising engine.
+
+Same constructor (tokenizer, text_encoder, vae, transformer, scheduler) and __call__ signature.  The
+denoise loop (PIPE.py:871-925) is restated in `denoise_step`: CFG batch order [uncond, cond], t.expand(B),
+transformer call, `uncond + g (cond - uncond)`, scheduler.step.  The per-video stages on either side of the
+loop (T5 prompt encoding, VAE encode of the control maps, VAE decode) belong to third-party modules that are
+out of this build's scope: they are used through the same attribute contract when
+the caller provides them, and can be bypassed with `prompt_embeds=` / `negative_prompt_embeds=`,
+`geoada_latents=` and `output_type="latent"`.
+"""
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import torch
+import torch.nn.functional as F
+
+from ..utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+
+@dataclass
+class WanPipelineOutput:
+    videos: torch.Tensor
+
+
+def geoada_encode_masks(masks, vae_stride=(4, 8, 8)) -> List[torch.Tensor]:
+    """PIPE.py:440-486 (ref_images=None): per sample [C,T,H,W] mask -> [64, (T+3)//4, H/8, W/8] by an 8x8
+    pixel-unshuffle of channel 0 and a nearest-exact resize of the frame axis."""
+    out = []
+    for mask in masks:
+        c, depth, height, width = mask.shape
+        new_depth = int((depth + 3) // vae_stride[0])
+        height = 2 * (int(height) // (vae_stride[1] * 2))
+        width = 2 * (int(width) // (vae_stride[2] * 2))
+        m = mask[0].view(depth, height, vae_stride[1], width, vae_stride[1])
+        m = m.permute(2, 4, 0, 1, 3).reshape(vae_stride[1] * vae_stride[2], depth, height, width)
+        out.append(F.interpolate(m.unsqueeze(0), size=(new_depth, height, width), mode="nearest-exact").squeeze(0))
+    return out
+
+
+def geoada_latent(z, m):
+    """PIPE.py:488."""
+    return [torch.cat([zz, mm], dim=0) for zz, mm in zip(z, m)]
+
+
+class WanVerseCrafterPipeline:
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
+        self.transformer, self.scheduler = transformer, scheduler
+        self._guidance_scale = 1.0
+        self._interrupt = False
+        self._device = None
+
+    # -- small parts of the DiffusionPipeline surface the CLI touches ---------------------------------
+    def to(self, device):
+        self._device = torch.device(device)
+        for m in (self.transformer, self.vae, self.text_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(device)
+        return self
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    @property
+    def _execution_device(self):
+        if self._device is not None:
+            return self._device
+        return next(self.transformer.parameters()).device
+
+    def check_inputs(self, prompt, height, width, negative_prompt, prompt_embeds=None, negative_prompt_embeds=None):
+        """PIPE.py:579-632."""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+
+    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds=None, negative_prompt_embeds=None,
+                      max_sequence_length=512, device=None):
+        """PIPE.py:284-363.  Returns two lists of [len_i, text_dim] tensors."""
+        def enc(p):
+            if self.tokenizer is None or self.text_encoder is None:
+                raise RuntimeError("no tokenizer / text_encoder: pass prompt_embeds and negative_prompt_embeds "
+                                   "(the umT5 encoder is outside this build's scope)")
+            p = [p] if isinstance(p, str) else p
+            ti = self.tokenizer(p, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                add_special_tokens=True, return_tensors="pt")
+            ids, mask = ti.input_ids.to(device), ti.attention_mask.to(device)
+            lens = mask.gt(0).sum(dim=1).long()
+            emb = self.text_encoder(ids, attention_mask=mask)[0]
+            return [u[:v] for u, v in zip(emb, lens)]
+        if prompt_embeds is None:
+            prompt_embeds = enc(prompt)
+        if do_cfg and negative_prompt_embeds is None:
+            negative_prompt_embeds = enc(negative_prompt if negative_prompt is not None else "")
+        as_list = lambda e: list(e) if isinstance(e, (list, tuple)) else [u for u in e]
+        return as_list(prompt_embeds), (as_list(negative_prompt_embeds) if do_cfg else None)
+
+    def geoada_encode_multi_frames(self, multi_frames):
+        """PIPE.py:397-438 (ref_images=None): VAE-encode each control video, concat per sample on channels."""
+        if self.vae is None:
+            raise RuntimeError("no VAE: pass geoada_latents (the Wan VAE is outside this build's scope)")
+        enc = [self.vae.encode(f)[0].mode() for f in multi_frames]
+        return [torch.cat(items, dim=0) for items in zip(*enc)]
+
+    def prepare_latents(self, batch_size, channels, shape_thw, dtype, device, generator, latents=None):
+        """PIPE.py:365-395."""
+        shape = (batch_size, channels, *shape_thw)
+        if latents is None:
+            gdev = generator.device if generator is not None else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        if hasattr(self.scheduler, "init_noise_sigma"):
+            latents = latents * self.scheduler.init_noise_sigma
+        return latents
+
+    # -- the hot loop body ----------------------------------------------------------------------------
+    def denoise_step(self, i, t, latents, in_prompt_embeds, geoada_context_input, seq_len, do_cfg,
+                     geoada_context_scale=1.0):
+        """One iteration of PIPE.py:871-925."""
+        self.transformer.current_steps = i
+        latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
+        if hasattr(self.scheduler, "scale_model_input"):
+            latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+        timestep = t.expand(latent_model_input.shape[0])
+        noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
+                                      geoada_context=geoada_context_input, seq_len=seq_len,
+                                      geoada_context_scale=geoada_context_scale)
+        if do_cfg:
+            noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+            noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)
+        return self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 720, video=None,
+                 mask_video=None, control_video=None, subject_ref_images=None, num_frames: int = 49,
+                 num_inference_steps: int = 50, timesteps=None, guidance_scale: float = 6,
+                 num_videos_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, output_type: str = "numpy", return_dict: bool = False,
+                 callback_on_step_end: Optional[Callable] = None, attention_kwargs=None,
+                 callback_on_step_end_tensor_inputs=("latents",), max_sequence_length: int = 512,
+                 comfyui_progressbar: bool = False, shift: int = 5, geoada_context_scale: float = 1.0,
+                 geoada_latents=None, mask_latents=None):
+        """PIPE.py:652-948.  Extensions (keyword-only in practice): `geoada_latents` (list of [64,T,h,w] control
+        latents, replacing the VAE encode) and `mask_latents` (list of [64,T,h,w])."""
+        if subject_ref_images is not None:
+            raise NotImplementedError("subject_ref_images is not used by the VerseCrafter CLI (CLI.py:431)")
+        num_videos_per_prompt = 1                                                   # PIPE.py:696
+        self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        batch_size = 1 if isinstance(prompt, str) else (len(prompt) if prompt is not None else len(prompt_embeds))
+        device = self._execution_device
+        weight_dtype = next(self.transformer.parameters()).dtype
+        do_cfg = guidance_scale > 1.0                                               # PIPE.py:726
+        pe, ne = self.encode_prompt(prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds,
+                                    max_sequence_length, device)
+        pe = [u.to(device=device, dtype=weight_dtype) for u in pe]
+        in_prompt_embeds = ([u.to(device=device, dtype=weight_dtype) for u in ne] + pe) if do_cfg else pe  # PIPE.py:741
+
+        if isinstance(self.scheduler, FlowUniPCMultistepScheduler):                # PIPE.py:750-752
+            self.scheduler.set_timesteps(num_inference_steps, device=device, shift=shift)
+        else:
+            self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+
+        # control maps -> geoada_context (PIPE.py:766-835)
+        if geoada_latents is None:
+            if control_video is None:
+                raise ValueError("control_video (or geoada_latents) is required")
+            vids = [(cv.to(torch.float32) * 2.0 - 1.0).to(dtype=weight_dtype, device=device) for cv in control_video]
+            geoada_latents = self.geoada_encode_multi_frames(vids)
+        geoada_latents = [z.to(device=device, dtype=weight_dtype) for z in geoada_latents]
+        if mask_latents is None:
+            if mask_video is None:
+                raise ValueError("mask_video (or mask_latents) is required")
+            mc = torch.tile(mask_video.to(torch.float32), [1, 3, 1, 1, 1]).to(dtype=weight_dtype, device=device)
+            mask_latents = geoada_encode_masks(mc)
+        mask_latents = [m.to(device=device, dtype=weight_dtype) for m in mask_latents]
+        geoada_context = geoada_latent(geoada_latents, mask_latents)                # [128, T, h, w] per sample
+
+        T, h, w = geoada_latents[0].shape[1:]
+        latent_channels = getattr(getattr(self.vae, "config", None), "latent_channels", 16)
+        latents = self.prepare_latents(batch_size * num_videos_per_prompt, latent_channels, (T, h, w), weight_dtype,
+                                       device, generator, latents)
+        seq_len = math.ceil((h * w) / (self.transformer.config.patch_size[1] * self.transformer.config.patch_size[2]) * T)
+        self.transformer.num_inference_steps = num_inference_steps                  # PIPE.py:869
+        # the reference re-stacks this every step (PIPE.py:883-887); it is step-invariant
+        geoada_context_input = torch.stack(geoada_context * 2) if do_cfg else torch.stack(geoada_context)
+
+        for i, t in enumerate(timesteps):                                           # PIPE.py:871
+            if self.interrupt:
+                continue
+            latents = self.denoise_step(i, t, latents, in_prompt_embeds, geoada_context_input, seq_len, do_cfg,
+                                        geoada_context_scale)
+            if callback_on_step_end is not None:
+                outs = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = outs.pop("latents", latents)
+
+        if output_type == "latent":
+            video = latents
+        else:                                                                       # PIPE.py:550-555, 932-946
+            if self.vae is None:
+                raise RuntimeError("no VAE to decode with: use output_type='latent'")
+            frames = self.vae.decode(latents.to(self.vae.dtype)).sample
+            video = (frames / 2 + 0.5).clamp(0, 1).cpu().float()
+        return WanPipelineOutput(videos=video)
