@@ -288,9 +288,11 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         self._rope_dirty = True
 
     def enable_multi_gpus_inference(self, sp_group=None):
-        """WT.py:901-921: switch self-attention of blocks and geoada_blocks to the Ulysses exchange."""
+        """WT.py:901-921: switch self-attention of blocks and geoada_blocks to the Ulysses exchange.
+        `sp_group`: a torch.distributed group (default: the one set_multi_gpus_devices made), or an object with
+        the SequenceParallel interface (world_size, rank, c_all_to_all, c_all_gather) -- tests inject one."""
         from .. import dist as vdist
-        self._sp = vdist.SequenceParallel(sp_group)
+        self._sp = sp_group if hasattr(sp_group, "c_all_to_all") else vdist.SequenceParallel(sp_group)
         self.sp_world_size = self._sp.world_size
         self.sp_world_rank = self._sp.rank
         self.all_gather = self._sp.all_gather_dim1
@@ -429,8 +431,11 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         out = torch.empty(B, self.out_dim, T, H, W, dtype=torch.bfloat16, device=x.device)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         with torch.cuda.device(x.device):
-            _lib.check(lib.vc_forward(h, C.c_void_p(xc.data_ptr()), C.c_void_p(tf.data_ptr()),
-                                      C.c_void_p(out.data_ptr()), float(geoada_context_scale), flags, stream), h)
+            rc = lib.vc_forward(h, C.c_void_p(xc.data_ptr()), C.c_void_p(tf.data_ptr()), C.c_void_p(out.data_ptr()),
+                                float(geoada_context_scale), flags, stream)
+        if rc != 0 and self._sp is not None and getattr(self._sp, "error", None) is not None:
+            raise RuntimeError("sequence-parallel collective failed inside vc_forward") from self._sp.error
+        _lib.check(rc, h)
         if self.teacache is not None and cond_flag:                                # VC.py:438-441
             self.teacache.cnt += 1
             if self.teacache.cnt == self.teacache.num_steps:
