@@ -295,7 +295,7 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         self._sp = sp_group if hasattr(sp_group, "c_all_to_all") else vdist.SequenceParallel(sp_group)
         self.sp_world_size = self._sp.world_size
         self.sp_world_rank = self._sp.rank
-        self.all_gather = self._sp.all_gather_dim1
+        self.all_gather = getattr(self._sp, "all_gather_dim1", None)
         self._sp_dirty = True
 
     # ------------------------------------------------------------------ engine plumbing
