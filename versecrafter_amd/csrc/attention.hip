@@ -17,6 +17,8 @@
 //    V chunks XOR (((row&3)<<2)|((row>>2)&3)) (conflict-free transposed reads).
 //  * workgroup -> (batch*head, q block) map is XCD-contiguous so the workgroups sharing one XCD's L2 walk
 //    the same K/V.
+#include <stdlib.h>
+
 #include "vc_common.h"
 #include "vc_kernels.h"
 
@@ -30,35 +32,160 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // K + V
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // double buffer = 64 KiB
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
 VC_DEVICE int k_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
-VC_DEVICE int v_off(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+VC_DEVICE int v_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+VC_DEVICE int v_off(int row, int ch) { return row * 256 + ((ch ^ v_swz(row)) << 4); }
 
+template <bool SEG>
 VC_DEVICE int64_t tok_off(int t, int64_t ts, int seg_len, int64_t ss) {
-    if (seg_len == 0) return (int64_t)t * ts;
+    if (!SEG) return (int64_t)t * ts;
     const int s = t / seg_len;
     return (int64_t)s * ss + (int64_t)(t - s * seg_len) * ts;
 }
 
-VC_DEVICE void issue_loads(const bf16_t* kp, const bf16_t* vp, const VcAttnParams& p, int t,
-                           int st_row, int st_ch, uint4 (&kreg)[4], uint4 (&vreg)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int key = t * KT + st_row + 16 * i;
-        key = key < p.Lk ? key : p.Lk - 1;
-        kreg[i] = *(const uint4*)(kp + tok_off(key, p.k_ts, p.seg_len, p.k_ss) + st_ch * 8);
-        vreg[i] = *(const uint4*)(vp + tok_off(key, p.v_ts, p.seg_len, p.v_ss) + st_ch * 8);
-    }
+typedef __attribute__((address_space(3))) char lds_char;
+
+// One LDS-DMA of 16 B per lane (LDS dest = M0 base + lane*16), issued through inline asm so that hipcc does not
+// see a pending LDS write: otherwise it drains vmcnt(0) in front of the next ds_read and the prefetch of tile
+// t+1 stops overlapping the math of tile t.  The wave waits for it itself (s_waitcnt vmcnt(0) at the loop top).
+VC_DEVICE void glds16_asm(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
 }
-VC_DEVICE void write_lds(char* buf, int st_row, int st_ch, const uint4 (&kreg)[4], const uint4 (&vreg)[4]) {
+
+// K/V tile t -> LDS stage `buf`: one wave-instruction fills 4 rows of 256 B; the chunk swizzle is applied to the
+// per-lane SOURCE address (the LDS image of a wave-instruction is lane-linear).
+template <bool SEG>
+VC_DEVICE void stage_kv(const bf16_t* kp, const bf16_t* vp, const VcAttnParams& p, int t, char* buf, int wave, int lane) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)buf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = st_row + 16 * i;
-        *(uint4*)(buf + k_off(row, st_ch)) = kreg[i];
-        *(uint4*)(buf + TILE_BYTES + v_off(row, st_ch)) = vreg[i];
+        const int row0 = __builtin_amdgcn_readfirstlane(wave * 16 + i * 4);
+        const int row = row0 + (lane >> 4), pc = lane & 15;
+        int key = t * KT + row;
+        key = key < p.Lk ? key : p.Lk - 1;
+        const bf16_t* ks = kp + tok_off<SEG>(key, p.k_ts, p.seg_len, p.k_ss) + ((pc ^ (row & 15)) << 3);
+        const bf16_t* vs = vp + tok_off<SEG>(key, p.v_ts, p.seg_len, p.v_ss) + ((pc ^ v_swz(row)) << 3);
+        glds16_asm(ks, __builtin_amdgcn_readfirstlane(lds0 + row0 * 256));
+        glds16_asm(vs, __builtin_amdgcn_readfirstlane(lds0 + TILE_BYTES + row0 * 256));
     }
 }
 
+struct AttnLaneConst {
+    unsigned koff[8];     // K image byte offset of this lane's row r, chunk ks*2+h          (+ kb*8192 + stage)
+    unsigned voff[4][2];  // V image byte offset for (db, half): keys +0..3 / +8..11 of step 0 (+ s*4096 + stage)
+};
+
+// one KV tile: S^T = K.Q^T, online softmax, O^T += V^T.P^T.  STAGE selects the LDS stage statically so that every
+// LDS read is (loop-invariant lane offset register) + (immediate).
+template <int STAGE, int VARIANT>
+VC_DEVICE void attn_tile(const char* smem, const AttnLaneConst& lc, const bf16x8 (&qf)[8], f32x16 (&O)[4], float& m_run,
+                         float& l_run, float c, int t, int k_len, int h) {
+    const char* kbuf = smem + STAGE * STAGE_BYTES;
+    const char* vbuf = kbuf + TILE_BYTES;
+    // ---- all 16 K fragments first, then the MFMA chain ----
+    bf16x8 kf[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[kb][ks] = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 S[2];
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], S[kb], 0, 0, 0);
+    }
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+    // V^T fragments of key steps 0,1 fly under the softmax
+    bf16x8 vfa[2][4], vfb[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][0] + s * 4096));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][1] + s * 4096));
+            vfa[s][db] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    if ((t + 1) * KT > k_len) {   // tile straddles k_len: mask keys >= k_len (block-uniform branch)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (key >= k_len) S[kb][e] = -1e30f;
+            }
+    }
+    // ---- online softmax (row = lane&31, duplicated on lane^32) ----
+    float mx = S[0][0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[0][e]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[1][e]);
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (__any(mx > m_run)) {      // some row of this wave has a new maximum: rescale (exact; else alpha == 1)
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+    }
+    const float mc = m_run * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(S[kb][e] * c - mc);
+            S[kb][e] = pe;
+            ps += pe;
+        }
+    l_run += ps;
+    // ---- O^T[d][q] += V^T[d][key] . P^T[key][q] ----
+    bf16x8 pf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[s][j] = (__bf16)S[s >> 1][8 * (s & 1) + j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][0] + (s + 2) * 4096));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][1] + (s + 2) * 4096));
+            vfb[s][db] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[s][db], pf[s], O[db], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[s][db], pf[s + 2], O[db], 0, 0, 0);
+    if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+}
+
+template <bool SEG, int VARIANT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(VcAttnParams p, int nQ, int nwork) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int per_xcd = gridDim.x >> 3;
@@ -78,19 +205,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(VcAttnParams p, int nQ
     const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
     const int nt = (k_len + KT - 1) / KT;
 
+    stage_kv<SEG>(kp, vp, p, 0, smem, wave, lane);
+
     // ---- Q fragment: B operand of S^T = K.Q^T : lane holds Q[q = r][d = ks*16 + 8h + 0..7] ----
     const int q_row = qb * QB + wave * 32 + r;
     const int q_row_c = q_row < p.Lq ? q_row : p.Lq - 1;
     bf16x8 qf[8];
     {
-        const bf16_t* qrow = qp + tok_off(q_row_c, p.q_ts, p.seg_len, p.q_ss) + 8 * h;
+        const bf16_t* qrow = qp + tok_off<SEG>(q_row_c, p.q_ts, p.seg_len, p.q_ss) + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 16);
+        // retire these (compiler-counted) loads here: a vmcnt wait left inside the loop would also drain the
+        // hand-issued LDS-DMA prefetch of the next tile
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
-    // ---- staging map: thread -> (row, 16-byte chunk) x 4 ----
-    const int st_row = tid >> 4, st_ch = tid & 15;   // rows st_row + 16*i
-    uint4 kreg[4], vreg[4];
+    // ---- loop-invariant per-lane LDS offsets ----
+    AttnLaneConst lc;
+    {
+        const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;   // transposed-read roles (T10)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) lc.koff[ks] = k_off(r, ks * 2 + h);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                lc.voff[db][hf] = v_off(4 * (g >> 1) + q4 + 8 * hf, db * 4 + 2 * (g & 1) + (p4 >> 1)) + 8 * (p4 & 1);
+    }
+
     f32x16 O[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -99,96 +242,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(VcAttnParams p, int nQ
     float m_run = -1e30f, l_run = 0.f;
     const float c = p.scale * 1.4426950408889634f;
 
-    issue_loads(kp, vp, p, 0, st_row, st_ch, kreg, vreg);
-    write_lds(smem, st_row, st_ch, kreg, vreg);
-    __syncthreads();
-
-    // transposed-read lane constants: group g = lane>>4 -> (h = g>>1, d half = g&1); in group: q4 = row, p4 = col quad
-    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-
-    for (int t = 0; t < nt; ++t) {
-        char* buf = smem + (t & 1) * STAGE_BYTES;
-        // next tile's loads fly under this tile's math (after the last tile: a harmless re-load)
-        issue_loads(kp, vp, p, (t + 1 < nt) ? t + 1 : t, st_row, st_ch, kreg, vreg);
-
-        // ---- S^T[key][q] for the two 32-key blocks ----
-        f32x16 S[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
-            const int krow = kb * 32 + r;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(buf + k_off(krow, ks * 2 + h));
-                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
-            }
-        }
-        if ((t + 1) * KT > k_len) {   // tile straddles k_len: mask keys >= k_len (block-uniform branch)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (key >= k_len) S[kb][e] = -1e30f;
-                }
-        }
-        // ---- online softmax (row = lane&31, duplicated on lane^32) ----
-        float mx = S[0][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[0][e]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[1][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        float ps = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(S[kb][e] * c - mc);
-                S[kb][e] = pe;
-                ps += pe;
-            }
-        l_run = l_run * alpha + ps;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
-
-        // ---- O^T[d][q] += V^T[d][key] . P^T[key][q] ----
-        const char* vbuf = buf + TILE_BYTES;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int kb = s >> 1, s2 = s & 1;
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)S[kb][8 * s2 + j];
-            const int key0 = s * 16 + 4 * (g >> 1) + q4;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const int ch = db * 4 + 2 * (g & 1) + (p4 >> 1);
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds_bf16x4*)(vbuf + v_off(key0, ch) + 8 * (p4 & 1)));
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds_bf16x4*)(vbuf + v_off(key0 + 8, ch) + 8 * (p4 & 1)));
-                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[db], 0, 0, 0);
-            }
-        }
-
-        write_lds(smem + ((t + 1) & 1) * STAGE_BYTES, st_row, st_ch, kreg, vreg);
+    for (int t = 0; t < nt; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();     // tile t landed for every wave; every wave finished reading stage 1
+        if (t + 1 < nt) stage_kv<SEG>(kp, vp, p, t + 1, smem + STAGE_BYTES, wave, lane);
+        attn_tile<0, VARIANT>(smem, lc, qf, O, m_run, l_run, c, t, k_len, h);
+        if (t + 1 >= nt) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (t + 2 < nt) stage_kv<SEG>(kp, vp, p, t + 2, smem, wave, lane);
+        attn_tile<1, VARIANT>(smem, lc, qf, O, m_run, l_run, c, t + 1, k_len, h);
     }
 
     // ---- epilogue: lane holds O[q = r][d = db*32 + 8*g4 + 4h + 0..3] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_row < p.Lq) {
-        bf16_t* orow = op + tok_off(q_row, p.o_ts, p.seg_len, p.o_ss) + 4 * h;
+        bf16_t* orow = op + tok_off<SEG>(q_row, p.o_ts, p.seg_len, p.o_ss) + 4 * h;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -200,16 +270,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(VcAttnParams p, int nQ
     }
 }
 
-}  // namespace
-
-int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
-    if (!p.q || !p.k || !p.v || !p.out || p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return VC_E_INVALID;
-    if ((p.q_ts | p.k_ts | p.v_ts | p.q_hs | p.k_hs | p.v_hs | p.q_bs | p.k_bs | p.v_bs) % 8) return VC_E_UNSUPPORTED;
-    if ((p.o_ts | p.o_hs | p.o_bs) % 4) return VC_E_UNSUPPORTED;
-    if (p.seg_len < 0 || (p.seg_len > 0 && ((p.q_ss | p.k_ss | p.v_ss) % 8 || p.o_ss % 4))) return VC_E_UNSUPPORTED;
+template <bool SEG, int VARIANT>
+int launch_attn(const VcAttnParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<SEG, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return VC_E_HIP;
         attr_set = true;
@@ -217,6 +282,18 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
     const int nQ = (p.Lq + QB - 1) / QB;
     const int nwork = p.B * p.H * nQ;
     const int grid = (nwork + 7) / 8 * 8;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), LDS_BYTES, stream, p, nQ, nwork);
+    hipLaunchKernelGGL((attn_fwd_kernel<SEG, VARIANT>), dim3(grid), dim3(256), LDS_BYTES, stream, p, nQ, nwork);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+}  // namespace
+
+int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
+    if (!p.q || !p.k || !p.v || !p.out || p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return VC_E_INVALID;
+    if ((p.q_ts | p.k_ts | p.v_ts | p.q_hs | p.k_hs | p.v_hs | p.q_bs | p.k_bs | p.v_bs) % 8) return VC_E_UNSUPPORTED;
+    if ((p.o_ts | p.o_hs | p.o_bs) % 4) return VC_E_UNSUPPORTED;
+    if (p.seg_len < 0 || (p.seg_len > 0 && ((p.q_ss | p.k_ss | p.v_ss) % 8 || p.o_ss % 4))) return VC_E_UNSUPPORTED;
+    static const int variant = getenv("VC_ATTN_VARIANT") ? atoi(getenv("VC_ATTN_VARIANT")) : 0;
+    if (p.seg_len > 0) return launch_attn<true, 0>(p, stream);
+    return variant == 1 ? launch_attn<false, 1>(p, stream) : launch_attn<false, 0>(p, stream);
 }
