@@ -117,20 +117,25 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
         if (kt + 1 < nk)
             stage_tile<Cfg>(A, p.lda, W, p.ldw, m0, n0, p.M, p.N, (kt + 1) * Cfg::BK,
                             smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES, tid, wave);
+        // all fragment reads of this K-step first (2 k-substeps x (MI + NI) ds_read_b128), then the MFMA chain:
+        // the LDS latency is paid once per K-step instead of once per group of MFMAs
+        bf16x8 af[2][MI], bfr[2][NI];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pc = ks ? pc1 : pc0;
-            bf16x8 af[MI], bfr[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(cur + a_row_off + i * 16 * 128 + pc);
+            for (int j = 0; j < NI; ++j) bfr[ks][j] = *(const bf16x8*)(cur + b_row_off + j * 16 * 128 + pc);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(cur + b_row_off + j * 16 * 128 + pc);
+            for (int i = 0; i < MI; ++i) af[ks][i] = *(const bf16x8*)(cur + a_row_off + i * 16 * 128 + pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
