@@ -5,8 +5,8 @@
 // 512 keys, no mask):  out = softmax(q k^T / sqrt(D)) v, keys >= k_len masked.
 //
 // Structure (CDNA4, 64-lane waves, v_mfma_f32_32x32x16_bf16):
-//  * workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows, its Q
-//    fragment lives in registers for the whole kernel.
+//  * workgroup = 8 waves = 256 query rows of one (batch, head) (4 waves / 128 rows when there are < 2048 keys); each
+//    wave owns 32 query rows, its Q fragment lives in registers for the whole kernel.
 //  * K/V tiles of 64 keys go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4 issued through inline asm with a
 //    hand-placed s_waitcnt, so hipcc does not drain it early), 2-deep rings, one barrier per tile;
 //  * software pipeline inside each wave: the MFMA chain of S(t+1) = K(t+1).Q^T is issued together with the
@@ -31,7 +31,6 @@
 namespace {
 
 constexpr int D = 128;
-constexpr int QB = 128;     // query rows per workgroup
 constexpr int KT = 64;      // keys per tile
 constexpr int TILE_BYTES = KT * D * 2;          // 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // K + V
@@ -86,8 +85,9 @@ VC_DEVICE unsigned row_byte_off(int key, int64_t ts, int seg_len, int64_t ss) {
     return (unsigned)(((int64_t)sg * ss + (int64_t)(key - sg * seg_len) * ts) * 2);
 }
 
-template <bool SEG, int VARIANT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(VcAttnParams p, int nQ, int nwork) {
+template <bool SEG, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams p, int nQ, int nwork) {
+    constexpr int QB = NW * 32;          // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int per_xcd = gridDim.x >> 3;
     const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -106,17 +106,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(VcAttnParams p, i
     const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
     const int nt = (k_len + KT - 1) / KT;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
-    const int row_in_tile0 = wave * 16 + (lane >> 4);     // + 4*i
+    constexpr int RPW = KT / NW;                          // tile rows staged per wave (16 or 8)
+    const int row_in_tile0 = wave * RPW + (lane >> 4);    // + 4*i
     const int pc = lane & 15;
 
     // stage K(t) / V(t): 4 wave-instructions each; rows clamped to Lk-1 (only the last tile can exceed)
     auto stage = [&](int t, bool do_k, bool do_v, int kst, int vst) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RPW / 4; ++i) {
             const int row = row_in_tile0 + 4 * i;
             int key = t * KT + row;
             key = key < p.Lk ? key : p.Lk - 1;
-            const int row0 = __builtin_amdgcn_readfirstlane(wave * 16 + 4 * i);
+            const int row0 = __builtin_amdgcn_readfirstlane(wave * RPW + 4 * i);
             if (do_k)
                 glds16_s(row_byte_off<SEG>(key, p.k_ts, p.seg_len, p.k_ss) + ((pc ^ (row & 15)) << 4), kp,
                          __builtin_amdgcn_readfirstlane(lds0 + P_KST + kst * TILE_BYTES + row0 * 256));
@@ -285,11 +286,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(VcAttnParams p, i
     }
 }
 
-template <bool SEG, int VARIANT>
+template <bool SEG, int NW>
 int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
+    constexpr int QB = NW * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<SEG, VARIANT>,
+        if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<SEG, NW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return VC_E_HIP;
         attr_set = true;
@@ -297,7 +299,7 @@ int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
     const int nQ = (p.Lq + QB - 1) / QB;
     const int nwork = p.B * p.H * nQ;
     const int grid = (nwork + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<SEG, VARIANT>), dim3(grid), dim3(256), LDS_BYTES, stream, p, nQ, nwork);
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<SEG, NW>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p, nQ, nwork);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 
@@ -314,5 +316,8 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
     const int64_t span_v = (p.seg_len > 0 ? (int64_t)((p.Lk - 1) / p.seg_len) * p.v_ss + (int64_t)p.seg_len * p.v_ts
                                           : (int64_t)p.Lk * p.v_ts) * 2;
     if (span_k >= (1ll << 32) || span_v >= (1ll << 32) || p.k_ts < 0 || p.v_ts < 0) return VC_E_UNSUPPORTED;
-    return p.seg_len > 0 ? launch_attn_pipe<true, 0>(p, stream) : launch_attn_pipe<false, 0>(p, stream);
+    // 256 query rows per workgroup (8 waves) halve the K/V LDS-DMA per FLOP on long sequences; short key sequences
+    // (T5 cross-attention, 512 keys) are prologue-dominated and run better with twice as many, smaller workgroups
+    if (p.Lk >= 2048) return p.seg_len > 0 ? launch_attn_pipe<true, 8>(p, stream) : launch_attn_pipe<false, 8>(p, stream);
+    return p.seg_len > 0 ? launch_attn_pipe<true, 4>(p, stream) : launch_attn_pipe<false, 4>(p, stream);
 }
