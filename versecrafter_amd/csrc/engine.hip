@@ -130,7 +130,9 @@ struct ProfScope {
 };
 
 int p_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, int cls = VC_PROF_GEMM) {
-    ProfScope ps(h, s, cls, 2.0 * g.M * g.N * (double)g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    const double ng = g.ngroups > 1 ? g.ngroups : 1;
+    ProfScope ps(h, s, cls, ng * 2.0 * g.M * g.N * (double)g.K,
+                 2.0 * ((double)g.M * g.K + ng * ((double)g.N * g.K + (double)g.M * g.N)));
     return vc_launch_gemm(g, s);
 }
 int p_attn(vc_engine* h, const VcAttnParams& a, hipStream_t s, int cls) {
@@ -255,11 +257,7 @@ int self_attention(vc_engine* h, hipStream_t s) {
     const int Nl = N / P;
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
     const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
-    for (int dst = 0; dst < P; ++dst)
-        for (int w = 0; w < 3; ++w)
-            VCCHK(h, vc_launch_copy_strided((const char*)h->qkv + ((int64_t)w * d + dst * hd) * 2,
-                                            (char*)h->a2a_send + ((int64_t)(dst * 3 + w) * blk) * 2, B * Lloc,
-                                            (int)hd, 3 * d, hd, s));
+    VCCHK(h, vc_launch_sp_pack_qkv(h->qkv, h->a2a_send, B * Lloc, d, P, s));
     if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, 3 * blk * 2, (void*)s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (q/k/v)");
     // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
@@ -277,9 +275,7 @@ int self_attention(vc_engine* h, hipStream_t s) {
     if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, blk * 2, (void*)s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (o)");
     // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
-    for (int src = 0; src < P; ++src)
-        VCCHK(h, vc_launch_copy_strided((const char*)h->a2a_recv + (int64_t)src * blk * 2,
-                                        (char*)h->attn + (int64_t)src * hd * 2, B * Lloc, (int)hd, hd, d, s));
+    VCCHK(h, vc_launch_sp_unpack_o(h->a2a_recv, h->attn, B * Lloc, d, P, s));
     return VC_OK;
 }
 
@@ -293,13 +289,12 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, h->mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
     { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
-    // q, k, v projections into [M, 3d]  (WT.py:385-387)
+    // q, k, v projections into [M, 3d]  (WT.py:385-387): one grouped launch (3 problems sharing A)
     {
         VcGemmParams g = gemm(h->tb, d, w.sa_q_w, w.sa_q_b, h->qkv, 3 * d, M, d, d);
-        VCCHK(h, p_gemm(h, g, s));
-        g = gemm(h->tb, d, w.sa_k_w, w.sa_k_b, (char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, d);
-        VCCHK(h, p_gemm(h, g, s));
-        g = gemm(h->tb, d, w.sa_v_w, w.sa_v_b, (char*)h->qkv + (int64_t)2 * d * 2, 3 * d, M, d, d);
+        g.ngroups = 3;
+        g.Wg[0] = w.sa_k_w; g.biasg[0] = w.sa_k_b; g.Cg[0] = (char*)h->qkv + (int64_t)d * 2;
+        g.Wg[1] = w.sa_v_w; g.biasg[1] = w.sa_v_b; g.Cg[1] = (char*)h->qkv + (int64_t)2 * d * 2;
         VCCHK(h, p_gemm(h, g, s));
     }
     // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)

@@ -85,13 +85,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
     const int first_m = group * GROUP_M;
     const int gsz = min(nTm - first_m, GROUP_M);
     const int tm = first_m + (id % width) % gsz;
-    const int tn = (id % width) / gsz;
+    int tn = (id % width) / gsz;
+    // grouped launch: the column-tile axis runs over the problems back to back (they share the A panel in L2)
+    const int nTn1 = p.ngroups > 1 ? nTn / p.ngroups : nTn;
+    const int grp = tn / nTn1;
+    tn -= grp * nTn1;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const bf16_t* A = (const bf16_t*)p.A;
-    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* W = (const bf16_t*)(grp == 0 ? p.W : p.Wg[grp - 1]);
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -139,11 +143,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    const bf16_t* bias = (const bf16_t*)p.bias;
+    const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
     const bf16_t* resid = (const bf16_t*)p.resid;
     const bf16_t* gate = (const bf16_t*)p.gate;
     const bf16_t* hint = (const bf16_t*)p.hint;
-    bf16_t* C = (bf16_t*)p.C;
+    bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -198,7 +202,8 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
         if (e != hipSuccess) return VC_E_HIP;
         attr_set = true;
     }
-    const int nTm = (p.M + Cfg::BM - 1) / Cfg::BM, nTn = (p.N + Cfg::BN - 1) / Cfg::BN;
+    const int ng = p.ngroups > 1 ? p.ngroups : 1;
+    const int nTm = (p.M + Cfg::BM - 1) / Cfg::BM, nTn = ng * ((p.N + Cfg::BN - 1) / Cfg::BN);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
     hipLaunchKernelGGL(gemm_bf16_kernel<Cfg>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, p, nTm, nTn,
@@ -217,6 +222,9 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID) && (!p.resid || p.ldr % 4))
         return VC_E_INVALID;
     if (p.epilogue == VC_EPI_BIAS_GATE_RESID && !p.gate) return VC_E_INVALID;
+    if (p.ngroups < 0 || p.ngroups > 3) return VC_E_INVALID;
+    for (int g = 1; g < p.ngroups; ++g)
+        if (!p.Wg[g - 1] || !p.Cg[g - 1]) return VC_E_INVALID;
     bool big = (p.M >= 1024 && p.N >= 256);
     if (vc_gemm_tile_override == 1) big = false;
     if (vc_gemm_tile_override == 2) big = true;

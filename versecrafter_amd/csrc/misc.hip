@@ -144,6 +144,26 @@ __global__ void copy_strided_kernel(const bf16_t* __restrict__ src, bf16_t* __re
     }
 }
 
+// Ulysses pack: qkv [M, 3*d] -> send [P][3][M][hd], hd = d / P   (16-byte chunks)
+__global__ void sp_pack_qkv_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ send, int M, int d8, int hd8) {
+    const int64_t n = (int64_t)M * 3 * d8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % (3 * d8)), row = (int)(i / (3 * d8));
+        const int w = col / d8, within = col - w * d8;
+        const int dst = within / hd8, c = within - dst * hd8;
+        ((uint4*)send)[((int64_t)(dst * 3 + w) * M + row) * hd8 + c] = ((const uint4*)qkv)[i];
+    }
+}
+// Ulysses unpack: recv [P][M][hd] -> attn [M, d]
+__global__ void sp_unpack_o_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ attn, int M, int d8, int hd8) {
+    const int64_t n = (int64_t)M * d8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % d8), row = (int)(i / d8);
+        const int src = col / hd8, c = col - src * hd8;
+        ((uint4*)attn)[i] = ((const uint4*)recv)[((int64_t)src * M + row) * hd8 + c];
+    }
+}
+
 inline int grid_for(int64_t n, int block) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -219,5 +239,19 @@ int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64
     if (!src || !dst || rows <= 0 || cols <= 0 || cols % 8 || src_ld % 8 || dst_ld % 8) return VC_E_INVALID;
     hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((int64_t)rows * cols / 8, 256)), dim3(256), 0, st,
                        (const bf16_t*)src, (bf16_t*)dst, rows, cols / 8, src_ld, dst_ld);
+    return ok();
+}
+
+int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st) {
+    if (!qkv || !send || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
+    hipLaunchKernelGGL(sp_pack_qkv_kernel, dim3(grid_for((int64_t)M * 3 * d / 8, 256)), dim3(256), 0, st,
+                       (const bf16_t*)qkv, (bf16_t*)send, M, d / 8, d / P / 8);
+    return ok();
+}
+
+int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st) {
+    if (!recv || !attn || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
+    hipLaunchKernelGGL(sp_unpack_o_kernel, dim3(grid_for((int64_t)M * d / 8, 256)), dim3(256), 0, st,
+                       (const bf16_t*)recv, (bf16_t*)attn, M, d / 8, d / P / 8);
     return ok();
 }

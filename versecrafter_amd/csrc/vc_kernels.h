@@ -30,6 +30,9 @@ struct VcGemmParams {
     const void* resid; int64_t ldr;  // bf16 [M, N] (may alias C)
     const void* gate;  int64_t gate_bstride;  // bf16, gate[b*gate_bstride + n], b = m / rows_per_batch
     const void* hint;  int64_t ldh;  float hint_scale;  // optional second residual (GATE_RESID only)
+    // grouped launch (q/k/v projections): up to 3 problems sharing A, M, N, K, ld*; group g > 0 uses Wg/biasg/Cg
+    int ngroups;                     // 0 or 1 -> single problem
+    const void* Wg[2]; const void* biasg[2]; void* Cg[2];
     int rows_per_batch;              // rows per sample (for gate and valid_rows); 0 -> M
     int valid_rows;                  // >= 0: rows with (m % rows_per_batch) >= valid_rows are written as 0; < 0: off
 };
@@ -84,6 +87,11 @@ int vc_launch_axpy(const void* a, const void* b, void* out, float s, int64_t n, 
 int vc_launch_sub(const void* a, const void* b, void* out, int64_t n, hipStream_t st);
 // zero-pad text rows: dst[b, i, :] = i < len[b] ? src_b[i, :] : 0      (VC.py:358-363)
 int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, hipStream_t st);
-// all-to-all pack/unpack for Ulysses (see engine.cpp)
+// Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py):
+//   pack   qkv [M, 3d]       -> send [P_dst][3][M][d/P]
+//   unpack recv [P_src][M][d/P] -> attn [M, d]
+int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st);
+int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st);
+// generic strided 2-D copy
 int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
                            hipStream_t st);
