@@ -197,9 +197,17 @@ def main():
             dom = max(("attn_self", "gemm"), key=lambda k: prof[k]["ms"])
             v = prof[dom]
             ach = v["flops"] / (v["ms"] / 1e3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": {"attn_self": "attn_fwd_kernel", "gemm": "gemm_bf16_kernel"}[dom],
+            kname = {"attn_self": "attn_fwd_pipe_kernel", "gemm": "gemm_bf16_kernel"}[dom]
+            traffic = None      # HBM bytes per launch come from the committed PMC passes (profiles/traffic.json), not live
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if tj.get("workload") == args.workload and tj.get("n_gpus") == world and kname in tj:
+                    traffic = tj[kname]["bytes_per_launch"]
+            except (OSError, ValueError):
+                pass
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
             out["breakdown"] = bd
         if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ def find(d, suffix):
 
 
 def short(name):
-    for k in ("attn_fwd_kernel", "gemm_bf16_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
+    for k in ("attn_fwd_pipe_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
               "unpatchify_kernel", "small_linear_kernel", "modulation_kernel", "axpy_kernel", "copy_strided_kernel"):
         if k in name:
             if k == "gemm_bf16_kernel":
@@ -37,15 +37,15 @@ def main():
               f"{float(r['AverageNs']) / 1e3:11.1f} {float(r['Percentage']):7.2f}")
     tr = find(stats_dir, "_kernel_trace.csv")
     if tr:
-        att = [r for r in csv.DictReader(open(tr)) if "attn_fwd_kernel" in r["Kernel_Name"]]
+        att = [r for r in csv.DictReader(open(tr)) if "attn_fwd" in r["Kernel_Name"]]
         att.sort(key=lambda r: int(r["Start_Timestamp"]))
         dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in att]
         big = [d for d in dur if d > 5e6]
         small = [d for d in dur if d <= 5e6]
         if big:
-            print(f"attn_fwd_kernel self-attention launches : {len(big)} avg {sum(big) / len(big) / 1e6:.3f} ms")
+            print(f"attention self-attention launches : {len(big)} avg {sum(big) / len(big) / 1e6:.3f} ms")
         if small:
-            print(f"attn_fwd_kernel cross-attention launches: {len(small)} avg {sum(small) / len(small) / 1e6:.3f} ms")
+            print(f"attention cross-attention launches: {len(small)} avg {sum(small) / len(small) / 1e6:.3f} ms")
     if len(sys.argv) >= 4:
         print()
         print("== PMC passes (separate runs): HBM-side traffic per launch, GiB ==")
@@ -58,9 +58,10 @@ def main():
                 if r["Counter_Name"] != ctr:
                     continue
                 k = short(r["Kernel_Name"])
-                if k == "attn_fwd_kernel":          # launches alternate self / cross inside every DiT block
-                    k += "[self]" if seen[k] % 2 == 0 else "[cross]"
-                    seen["attn_fwd_kernel"] += 1
+                if k.startswith("attn_fwd"):          # launches alternate self / cross inside every DiT block
+                    base = k
+                    k += "[self]" if seen[base] % 2 == 0 else "[cross]"
+                    seen[base] += 1
                 agg[k][ctr] += float(r["Counter_Value"])
                 if ctr == "FETCH_SIZE":
                     agg[k]["n"] += 1
