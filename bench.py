@@ -102,7 +102,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("VC_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the N>1 plumbing at N=1
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
@@ -119,7 +120,7 @@ def main():
     torch.manual_seed(0)
     model = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16, **mk)
     model.init_weights(zero_init_outputs=False)
-    if world > 1:
+    if use_dist:
         from versecrafter_amd import dist as vdist
         vdist._SP_GROUP = dist.group.WORLD
         model.enable_multi_gpus_inference()
@@ -148,7 +149,7 @@ def main():
         return lat
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +166,7 @@ def main():
         prof = model.profile_read()
         model.profile_enable(False)
     finite = bool(torch.isfinite(lat.float()).all().item())
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -213,7 +214,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mk, f_step)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -123,3 +123,36 @@ def test_sp_equals_single_rank_bitwise(P, seq_len):
         assert errs[r] is None, (r, errs[r], sps[r].error)
         assert sps[r].calls == 2 * 6            # two exchanges per self-attention, 4 main + 2 adapter blocks
         assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
+
+
+def test_collective_callbacks_on_rccl_world1():
+    """The production callbacks (versecrafter_amd.dist.SequenceParallel) on the real backend: torch.distributed
+    "nccl" (= RCCL) with a 1-rank world on this GPU -- all_to_all_single / all_gather_into_tensor on uint8 tensors
+    that alias raw device pointers (as the engine hands them over), on the current stream."""
+    import socket
+    import torch.distributed as dist
+    from versecrafter_amd import dist as vdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sp = vdist.SequenceParallel(dist.group.WORLD)
+        assert sp.world_size == 1 and sp.rank == 0
+        n = 1 << 20
+        send = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
+        recv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        assert sp._a2a(None, send.data_ptr(), recv.data_ptr(), n, stream) == 0, sp.error
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        recv.zero_()
+        assert sp._ag(None, send.data_ptr(), recv.data_ptr(), n, stream) == 0, sp.error
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        y = torch.randn(2, 5, 64, device="cuda").bfloat16()
+        assert torch.equal(sp.all_gather_dim1(y), y)
+    finally:
+        if created:
+            dist.destroy_process_group()
