@@ -24,10 +24,14 @@ class FakeComm:
         self.P = P
         self.barrier = threading.Barrier(P)
         self.slots = [None] * P
+        self.ready = [None] * P      # event: this rank's send buffer is complete on its stream
+        self.done = [None] * P       # event: this rank's copies out of the peers' send buffers are complete
 
 
 class FakeSP:
-    """SequenceParallel interface backed by device-to-device copies inside one process."""
+    """SequenceParallel interface backed by device-to-device copies inside one process.  Every rank's callback runs on
+    the HIP stream the engine passes in (main chain: the caller's stream; adapter chain: an engine-owned stream), so
+    the exchange orders the streams of the ranks with events exactly as a real collective would."""
 
     def __init__(self, comm, rank):
         from versecrafter_amd import _lib
@@ -42,15 +46,34 @@ class FakeSP:
     def _view(self, ptr, n):
         return self.alias(ptr, n, torch.device("cuda", 0))
 
+    def _exchange(self, send, stream, copy_fn):
+        c, P = self.comm, self.world_size
+        st = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+        ev = torch.cuda.Event()
+        ev.record(st)
+        c.slots[self.rank], c.ready[self.rank] = send, ev
+        c.barrier.wait()                                    # every rank has enqueued its producer kernels
+        with torch.cuda.stream(st):
+            for src in range(P):
+                st.wait_event(c.ready[src])
+            copy_fn(c.slots)
+            dn = torch.cuda.Event()
+            dn.record(st)
+        c.done[self.rank] = dn
+        c.barrier.wait()                                    # all copies enqueued ...
+        for r in range(P):
+            st.wait_event(c.done[r])                        # ... and finished before this rank reuses its buffers
+        c.barrier.wait()
+
     def _a2a(self, ctx, send, recv, bpp, stream):
         try:
-            c, P = self.comm, self.world_size
-            c.slots[self.rank] = send
-            c.barrier.wait()                                    # every rank has enqueued its pack kernels
-            r = self._view(recv, bpp * P)
-            for src in range(P):
-                r[src * bpp:(src + 1) * bpp].copy_(self._view(c.slots[src], bpp * P)[self.rank * bpp:(self.rank + 1) * bpp])
-            c.barrier.wait()                                    # all copies enqueued before anyone reuses `send`
+            P = self.world_size
+
+            def copy(slots):
+                r = self._view(recv, bpp * P)
+                for src in range(P):
+                    r[src * bpp:(src + 1) * bpp].copy_(self._view(slots[src], bpp * P)[self.rank * bpp:(self.rank + 1) * bpp])
+            self._exchange(send, stream, copy)
             self.calls += 1
             return 0
         except Exception as e:
@@ -59,13 +82,13 @@ class FakeSP:
 
     def _ag(self, ctx, send, recv, n, stream):
         try:
-            c, P = self.comm, self.world_size
-            c.slots[self.rank] = send
-            c.barrier.wait()
-            r = self._view(recv, n * P)
-            for src in range(P):
-                r[src * n:(src + 1) * n].copy_(self._view(c.slots[src], n))
-            c.barrier.wait()
+            P = self.world_size
+
+            def copy(slots):
+                r = self._view(recv, n * P)
+                for src in range(P):
+                    r[src * n:(src + 1) * n].copy_(self._view(slots[src], n))
+            self._exchange(send, stream, copy)
             return 0
         except Exception as e:
             self.error = e

@@ -22,16 +22,22 @@ class LoopbackSP:
         self.c_all_to_all = _lib.ALL_TO_ALL_FN(self._a2a)
         self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
 
+    @staticmethod
+    def _on(stream):
+        return torch.cuda.stream(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
+
     def _a2a(self, ctx, send, recv, bpp, stream):
         n = bpp * self.world_size
-        alias_device_bytes(recv, n, "cuda").copy_(alias_device_bytes(send, n, "cuda"))
+        with self._on(stream):
+            alias_device_bytes(recv, n, "cuda").copy_(alias_device_bytes(send, n, "cuda"))
         return 0
 
     def _ag(self, ctx, send, recv, n, stream):
-        r = alias_device_bytes(recv, n * self.world_size, "cuda")
-        s = alias_device_bytes(send, n, "cuda")
-        for i in range(self.world_size):
-            r[i * n:(i + 1) * n].copy_(s)
+        with self._on(stream):
+            r = alias_device_bytes(recv, n * self.world_size, "cuda")
+            s = alias_device_bytes(send, n, "cuda")
+            for i in range(self.world_size):
+                r[i * n:(i + 1) * n].copy_(s)
         return 0
 
 

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -44,6 +45,13 @@ struct BlockW {
 };
 
 thread_local std::string g_create_error;
+
+// scratch buffers + stream of one block chain.  Lane 0 = main chain on the caller's stream; lane 1 = GeoAdapter chain on
+// an engine-owned stream (used when the two chains run concurrently, see vc_forward).
+struct Lane {
+    hipStream_t s = nullptr;
+    void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
+};
 
 }  // namespace
 
@@ -74,8 +82,13 @@ struct vc_engine {
     // workspace
     char* arena = nullptr;
     int64_t arena_bytes = 0;
-    void *x, *c, *tb, *qkv, *attn, *hb, *hint, *c0, *x0, *resid, *patchA, *ctxpad, *ctxh, *ctx, *mod, *headmod, *ybuf,
-        *yfull, *a2a_send, *a2a_recv;
+    void *x, *c, *c0, *x0, *resid, *patchA, *ctxpad, *ctxh, *ctx, *headmod, *ybuf, *yfull;
+    void* hint[2];                  // hint ring (2 slots when the chains run concurrently)
+    Lane lane[2];
+    bool dual = false;              // adapter chain on its own stream (sequence-parallel runs: hides the exchanges)
+    hipStream_t s_adp = nullptr;
+    hipEvent_t ev_x = nullptr, ev_bp = nullptr;
+    std::vector<hipEvent_t> ev_hint, ev_used;
     float *f_sin, *f_h, *f_e, *f_e0;
     void* small = nullptr;   // fp32 scratch for vc_time_embedding before prepare
 
@@ -235,20 +248,21 @@ int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, fl
     return VC_OK;
 }
 
-// self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into h->attn
-int self_attention(vc_engine* h, hipStream_t s) {
+// self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into ln.attn
+int self_attention(vc_engine* h, Lane& ln) {
+    hipStream_t s = ln.s;
     const int d = h->cfg.dim, N = h->cfg.num_heads, B = h->B, Lloc = h->Lloc, P = h->P;
     VcAttnParams a;
     memset(&a, 0, sizeof a);
     a.scale = 1.0f / sqrtf(128.0f);
     a.B = B;
     if (P == 1) {
-        const char* q = (const char*)h->qkv;
+        const char* q = (const char*)ln.qkv;
         a.q = q; a.k = q + (int64_t)d * 2; a.v = q + (int64_t)2 * d * 2;
         a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * 3 * d;
         a.q_ts = a.k_ts = a.v_ts = 3 * d;
         a.q_hs = a.k_hs = a.v_hs = 128;
-        a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
+        a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.H = N; a.Lq = Lloc; a.Lk = Lloc; a.k_len = h->L;
         VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
         return VC_OK;
@@ -257,11 +271,11 @@ int self_attention(vc_engine* h, hipStream_t s) {
     const int Nl = N / P;
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
     const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
-    VCCHK(h, vc_launch_sp_pack_qkv(h->qkv, h->a2a_send, B * Lloc, d, P, s));
-    if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, 3 * blk * 2, (void*)s) != 0)
+    VCCHK(h, vc_launch_sp_pack_qkv(ln.qkv, ln.send, B * Lloc, d, P, s));
+    if (h->a2a(h->cb_ctx, ln.send, ln.recv, 3 * blk * 2, (void*)s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (q/k/v)");
     // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
-    const char* r = (const char*)h->a2a_recv;
+    const char* r = (const char*)ln.recv;
     a.q = r; a.k = r + blk * 2; a.v = r + 2 * blk * 2;
     a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * hd;
     a.q_ts = a.k_ts = a.v_ts = hd;
@@ -269,78 +283,83 @@ int self_attention(vc_engine* h, hipStream_t s) {
     a.seg_len = Lloc;
     a.q_ss = a.k_ss = a.v_ss = 3 * blk;
     // out (send buffer of the return exchange): [P_dst][B][Lloc][Nl][128]
-    a.out = h->a2a_send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
+    a.out = ln.send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
     VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
-    if (h->a2a(h->cb_ctx, h->a2a_send, h->a2a_recv, blk * 2, (void*)s) != 0)
+    if (h->a2a(h->cb_ctx, ln.send, ln.recv, blk * 2, (void*)s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (o)");
     // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
-    VCCHK(h, vc_launch_sp_unpack_o(h->a2a_recv, h->attn, B * Lloc, d, P, s));
+    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * Lloc, d, P, s));
     return VC_OK;
 }
 
 // WanAttentionBlock.forward (WT.py:564-611) on stream buffer xs, in place.  hint (optional): VC.py:146-147.
-int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, hipStream_t s) {
+// wait_hint / done: optional events -- wait on the lane stream right before the FFN-2 GEMM that reads `hint`, record after it.
+int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, Lane& ln,
+              hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr) {
+    hipStream_t s = ln.s;
     const int d = h->cfg.dim, f = h->cfg.ffn_dim, M = h->M, B = h->B, Lloc = h->Lloc, TL = h->cfg.text_len;
     const float eps = h->cfg.eps;
-    const char* mod = (const char*)h->mod;
+    const char* mod = (const char*)ln.mod;
     auto modp = [&](int j) { return (const void*)(mod + (int64_t)j * d * 2); };
     // e = modulation + e0  (WT.py:588)
-    VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, h->mod, B, 6, d, 6 * d, d, s));
+    VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, ln.mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
     // q, k, v projections into [M, 3d]  (WT.py:385-387): one grouped launch (3 problems sharing A)
     {
-        VcGemmParams g = gemm(h->tb, d, w.sa_q_w, w.sa_q_b, h->qkv, 3 * d, M, d, d);
+        VcGemmParams g = gemm(ln.tb, d, w.sa_q_w, w.sa_q_b, ln.qkv, 3 * d, M, d, d);
         g.ngroups = 3;
-        g.Wg[0] = w.sa_k_w; g.biasg[0] = w.sa_k_b; g.Cg[0] = (char*)h->qkv + (int64_t)d * 2;
-        g.Wg[1] = w.sa_v_w; g.biasg[1] = w.sa_v_b; g.Cg[1] = (char*)h->qkv + (int64_t)2 * d * 2;
+        g.Wg[0] = w.sa_k_w; g.biasg[0] = w.sa_k_b; g.Cg[0] = (char*)ln.qkv + (int64_t)d * 2;
+        g.Wg[1] = w.sa_v_w; g.biasg[1] = w.sa_v_b; g.Cg[1] = (char*)ln.qkv + (int64_t)2 * d * 2;
         VCCHK(h, p_gemm(h, g, s));
     }
     // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)h->qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)ln.qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
     {
-        int r = self_attention(h, s);
+        int r = self_attention(h, ln);
         if (r != VC_OK) return r;
     }
     // x = x + o(attn) * e2  (WT.py:404, 595)
     {
-        VcGemmParams g = gemm(h->attn, d, w.sa_o_w, w.sa_o_b, xs, d, M, d, d, VC_EPI_BIAS_GATE_RESID);
+        VcGemmParams g = gemm(ln.attn, d, w.sa_o_w, w.sa_o_b, xs, d, M, d, d, VC_EPI_BIAS_GATE_RESID);
         g.resid = xs; g.ldr = d; g.gate = modp(2); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
         VCCHK(h, p_gemm(h, g, s));
     }
     // cross attention: x = x + o(attn(rms(q(norm3(x))), K, V))  (WT.py:600, 410-436)
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s)); }
     {
-        VcGemmParams g = gemm(h->tb, d, w.ca_q_w, w.ca_q_b, h->qkv, d, M, d, d);
+        VcGemmParams g = gemm(ln.tb, d, w.ca_q_w, w.ca_q_b, ln.qkv, d, M, d, d);
         VCCHK(h, p_gemm(h, g, s));
     }
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(h->qkv, d, M, d, w.ca_nq, eps, nullptr, nullptr, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, d, M, d, w.ca_nq, eps, nullptr, nullptr, s)); }
     {
         VcAttnParams a;
         memset(&a, 0, sizeof a);
         a.scale = 1.0f / sqrtf(128.0f);
-        a.q = h->qkv; a.q_bs = (int64_t)Lloc * d; a.q_ts = d; a.q_hs = 128;
+        a.q = ln.qkv; a.q_bs = (int64_t)Lloc * d; a.q_ts = d; a.q_hs = 128;
         a.k = w.ck; a.k_bs = (int64_t)TL * d; a.k_ts = d; a.k_hs = 128;
         a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
-        a.out = h->attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
+        a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
         VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_CROSS));
-        VcGemmParams g = gemm(h->attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
+        VcGemmParams g = gemm(ln.attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
         g.resid = xs; g.ldr = d;
         VCCHK(h, p_gemm(h, g, s));
     }
     // ffn: x = x + ffn(norm2(x) * (1 + e4) + e3) * e5  (WT.py:603-607)  [+ hint * scale, VC.py:147]
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, h->tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s)); }
     {
-        VcGemmParams g = gemm(h->tb, d, w.f0_w, w.f0_b, h->hb, f, M, f, d, VC_EPI_BIAS_GELU);
+        VcGemmParams g = gemm(ln.tb, d, w.f0_w, w.f0_b, ln.hb, f, M, f, d, VC_EPI_BIAS_GELU);
         VCCHK(h, p_gemm(h, g, s));
-        g = gemm(h->hb, f, w.f2_w, w.f2_b, xs, d, M, d, f, VC_EPI_BIAS_GATE_RESID);
+        g = gemm(ln.hb, f, w.f2_w, w.f2_b, xs, d, M, d, f, VC_EPI_BIAS_GATE_RESID);
         g.resid = xs; g.ldr = d; g.gate = modp(5); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
         g.hint = hint; g.ldh = d; g.hint_scale = hint_scale;
+        if (wait_hint) HIPCHK(h, hipStreamWaitEvent(s, wait_hint, 0));
         VCCHK(h, p_gemm(h, g, s));
+        if (done) HIPCHK(h, hipEventRecord(done, s));
     }
     return VC_OK;
 }
@@ -426,12 +445,27 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     // fp32 scratch for the time embedding (B <= 8)
     const int64_t small_bytes = 8 * (int64_t)(cfg->freq_dim + 2 * d + 6 * d) * 4;
     if (hipMalloc(&h->small, small_bytes) != hipSuccess) { delete h; return fail(nullptr, VC_E_NOMEM, "hipMalloc(time scratch) failed"); }
+    // second chain: stream + events (created up front: nothing is created inside vc_forward)
+    const size_t na = h->geoada_layers.size();
+    h->ev_hint.resize(na); h->ev_used.resize(na);
+    bool ok = hipStreamCreateWithFlags(&h->s_adp, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_bp, hipEventDisableTiming) == hipSuccess;
+    for (size_t i = 0; ok && i < na; ++i)
+        ok = hipEventCreateWithFlags(&h->ev_hint[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_used[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { vc_destroy(h); return fail(nullptr, VC_E_HIP, "vc_create: stream/event creation failed"); }
     *out = h;
     return VC_OK;
 }
 
 void vc_destroy(vc_engine* h) {
     if (!h) return;
+    if (h->s_adp) { (void)hipStreamSynchronize(h->s_adp); (void)hipStreamDestroy(h->s_adp); }
+    if (h->ev_x) (void)hipEventDestroy(h->ev_x);
+    if (h->ev_bp) (void)hipEventDestroy(h->ev_bp);
+    for (auto e : h->ev_hint) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev_used) if (e) (void)hipEventDestroy(e);
     free_arena(h);
     if (h->rope_dev) (void)hipFree(h->rope_dev);
     if (h->small) (void)hipFree(h->small);
@@ -510,17 +544,27 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return o; };
     const int64_t md = (int64_t)M * d * 2;
-    const int64_t o_x = take(md), o_c = take(md), o_tb = take(md), o_qkv = take(3 * md), o_attn = take(md),
-                  o_hb = take((int64_t)M * f * 2), o_hint = take(md), o_c0 = take(md), o_x0 = take(md),
-                  o_resid = take(md);
+    h->dual = (P > 1) || (getenv("VC_DUAL_LANE") && atoi(getenv("VC_DUAL_LANE")) == 1);
+    const int nlanes = h->dual ? 2 : 1;
+    const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md), o_x0 = take(md), o_resid = take(md);
+    int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2];
+    for (int l = 0; l < 2; ++l) {
+        if (l < nlanes) {
+            o_hint[l] = take(md); o_tb[l] = take(md); o_qkv[l] = take(3 * md); o_attn[l] = take(md);
+            o_hb[l] = take((int64_t)M * f * 2); o_mod[l] = take((int64_t)B * 6 * d * 2);
+            o_send[l] = take(P > 1 ? 3 * md : 256); o_recv[l] = take(P > 1 ? 3 * md : 256);
+        } else {
+            o_hint[l] = o_hint[0]; o_tb[l] = o_tb[0]; o_qkv[l] = o_qkv[0]; o_attn[l] = o_attn[0]; o_hb[l] = o_hb[0];
+            o_mod[l] = o_mod[0]; o_send[l] = o_send[0]; o_recv[l] = o_recv[0];
+        }
+    }
     const int kmax = (c.geoada_in_dim > c.in_dim ? c.geoada_in_dim : c.in_dim) * 4;
     const int64_t o_patch = take((int64_t)M * kmax * 2);
     const int64_t o_ctxpad = take((int64_t)B * TL * c.text_dim * 2), o_ctxh = take((int64_t)B * TL * d * 2),
                   o_ctx = take((int64_t)B * TL * d * 2);
-    const int64_t o_mod = take((int64_t)B * 6 * d * 2), o_headmod = take((int64_t)B * 2 * d * 2);
+    const int64_t o_headmod = take((int64_t)B * 2 * d * 2);
     const int64_t yb = (int64_t)M * c.out_dim * 4 * 2;
     const int64_t o_y = take(yb), o_yfull = take(yb * P);
-    const int64_t o_send = take(P > 1 ? 3 * md : 256), o_recv = take(P > 1 ? 3 * md : 256);
     const int64_t o_fsin = take((int64_t)B * c.freq_dim * 4), o_fh = take((int64_t)B * d * 4),
                   o_fe = take((int64_t)B * d * 4), o_fe0 = take((int64_t)B * 6 * d * 4);
     const int64_t kvb = (int64_t)B * TL * d * 2;
@@ -532,10 +576,15 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     }
     h->arena_bytes = off;
     char* a = h->arena;
-    h->x = a + o_x; h->c = a + o_c; h->tb = a + o_tb; h->qkv = a + o_qkv; h->attn = a + o_attn; h->hb = a + o_hb;
-    h->hint = a + o_hint; h->c0 = a + o_c0; h->x0 = a + o_x0; h->resid = a + o_resid; h->patchA = a + o_patch;
-    h->ctxpad = a + o_ctxpad; h->ctxh = a + o_ctxh; h->ctx = a + o_ctx; h->mod = a + o_mod; h->headmod = a + o_headmod;
-    h->ybuf = a + o_y; h->yfull = a + o_yfull; h->a2a_send = a + o_send; h->a2a_recv = a + o_recv;
+    h->x = a + o_x; h->c = a + o_c; h->c0 = a + o_c0; h->x0 = a + o_x0; h->resid = a + o_resid; h->patchA = a + o_patch;
+    h->ctxpad = a + o_ctxpad; h->ctxh = a + o_ctxh; h->ctx = a + o_ctx; h->headmod = a + o_headmod;
+    h->ybuf = a + o_y; h->yfull = a + o_yfull;
+    for (int l = 0; l < 2; ++l) {
+        h->hint[l] = a + o_hint[l];
+        Lane& ln = h->lane[l];
+        ln.tb = a + o_tb[l]; ln.qkv = a + o_qkv[l]; ln.attn = a + o_attn[l]; ln.hb = a + o_hb[l]; ln.mod = a + o_mod[l];
+        ln.send = a + o_send[l]; ln.recv = a + o_recv[l];
+    }
     h->f_sin = (float*)(a + o_fsin); h->f_h = (float*)(a + o_fh); h->f_e = (float*)(a + o_fe);
     h->f_e0 = (float*)(a + o_fe0);
     for (int i = 0; i < nblk; ++i) {
@@ -612,30 +661,78 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     // ---- time embeddings (VC.py:347-354) ----
     { int r = time_embed(h, t, B, h->f_sin, h->f_h, h->f_e, h->f_e0, s); if (r != VC_OK) return r; }
 
+    Lane& L0 = h->lane[0];
+    L0.s = s;
     if (run_main) {
         if (store_res) HIPCHK(h, hipMemcpyAsync(h->x0, h->x, md, hipMemcpyDeviceToDevice, s));
-        // c = before_proj(c0) + x   (VC.py:113-114)
-        {
-            const BlockW& g0 = h->gblocks[0];
-            VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
-            g.resid = h->x; g.ldr = d;
-            VCCHK(h, p_gemm(h, g, s));
-        }
-        size_t next_adapter = 0;
-        for (int i = 0; i < c.num_layers; ++i) {
-            const int hn = h->layer_to_hint[i];
-            if (hn >= 0) {
-                while ((int)next_adapter <= hn) {            // adapter block n, then hint_n = after_proj(c)
-                    const BlockW& gb = h->gblocks[next_adapter];
-                    int r = run_block(h, gb, h->c, nullptr, 0.f, s);
+        const int NA = (int)h->gblocks.size();
+        // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
+        auto adapter_block = [&](int n, Lane& la, int nslots) -> int {
+            const BlockW& gb = h->gblocks[n];
+            int r = run_block(h, gb, h->c, nullptr, 0.f, la);
+            if (r != VC_OK) return r;
+            VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint[n % nslots], d, M, d, d);
+            VCCHK(h, p_gemm(h, g, la.s));
+            return VC_OK;
+        };
+        if (!h->dual) {
+            // c = before_proj(c0) + x   (VC.py:113-114)
+            {
+                const BlockW& g0 = h->gblocks[0];
+                VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
+                g.resid = h->x; g.ldr = d;
+                VCCHK(h, p_gemm(h, g, s));
+            }
+            int next_adapter = 0;
+            for (int i = 0; i < c.num_layers; ++i) {
+                const int hn = h->layer_to_hint[i];
+                if (hn >= 0)
+                    while (next_adapter <= hn) {             // adapter block n right before the layer that needs hint n
+                        int r = adapter_block(next_adapter, L0, 1);
+                        if (r != VC_OK) return r;
+                        ++next_adapter;
+                    }
+                int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint[0] : nullptr, geoada_context_scale, L0);
+                if (r != VC_OK) return r;
+            }
+        } else {
+            // The adapter chain depends on the main chain only through the initial x (VC.py:114), so it runs on its own
+            // stream, at most two blocks ahead of the main layer that consumes its hints (2-slot hint ring): while one
+            // chain waits for an Ulysses exchange the other chain's kernels keep the GPU busy.
+            Lane& L1 = h->lane[1];
+            L1.s = h->s_adp;
+            HIPCHK(h, hipEventRecord(h->ev_x, s));                       // x, e, e0 ready
+            HIPCHK(h, hipStreamWaitEvent(L1.s, h->ev_x, 0));
+            {
+                const BlockW& g0 = h->gblocks[0];
+                VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
+                g.resid = h->x; g.ldr = d;
+                VCCHK(h, p_gemm(h, g, L1.s));
+            }
+            HIPCHK(h, hipEventRecord(h->ev_bp, L1.s));
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_bp, 0));               // main blocks overwrite x in place
+            int issued = 0;
+            auto issue_adapter = [&](int n) -> int {                     // slot n%2 must have been consumed (hint n-2)
+                if (n >= 2) HIPCHK(h, hipStreamWaitEvent(L1.s, h->ev_used[n - 2], 0));
+                int r = adapter_block(n, L1, 2);
+                if (r != VC_OK) return r;
+                HIPCHK(h, hipEventRecord(h->ev_hint[n], L1.s));
+                return VC_OK;
+            };
+            for (; issued < NA && issued < 2; ++issued) { int r = issue_adapter(issued); if (r != VC_OK) return r; }
+            for (int i = 0; i < c.num_layers; ++i) {
+                const int hn = h->layer_to_hint[i];
+                if (hn >= 0) {
+                    while (issued <= hn) { int r = issue_adapter(issued); if (r != VC_OK) return r; ++issued; }
+                    int r = run_block(h, h->blocks[i], h->x, h->hint[hn % 2], geoada_context_scale, L0, h->ev_hint[hn],
+                                      h->ev_used[hn]);
                     if (r != VC_OK) return r;
-                    VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint, d, M, d, d);
-                    VCCHK(h, p_gemm(h, g, s));
-                    ++next_adapter;
+                    if (issued < NA && issued <= hn + 2) { r = issue_adapter(issued); if (r != VC_OK) return r; ++issued; }
+                } else {
+                    int r = run_block(h, h->blocks[i], h->x, nullptr, geoada_context_scale, L0);
+                    if (r != VC_OK) return r;
                 }
             }
-            int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint : nullptr, geoada_context_scale, s);
-            if (r != VC_OK) return r;
         }
         if (store_res) {                                     // previous_residual_cond = x - ori_x (VC.py:409)
             VCCHK(h, vc_launch_sub(h->x, h->x0, h->resid, (int64_t)M * d, s));
@@ -647,10 +744,10 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
 
     // ---- head (WT.py:631-644) ----
     VCCHK(h, vc_launch_modulation(h->head_mod, h->f_e, h->headmod, B, 2, d, d, 0, s));   // e broadcast over 2 rows
-    VCCHK(h, vc_launch_layernorm(h->x, h->tb, M, d, Lloc, c.eps, 0, (char*)h->headmod + (int64_t)d * 2, h->headmod,
+    VCCHK(h, vc_launch_layernorm(h->x, L0.tb, M, d, Lloc, c.eps, 0, (char*)h->headmod + (int64_t)d * 2, h->headmod,
                                  2 * d, s));
     {
-        VcGemmParams g = gemm(h->tb, d, h->head_w, h->head_b, h->ybuf, c.out_dim * 4, M, c.out_dim * 4, d);
+        VcGemmParams g = gemm(L0.tb, d, h->head_w, h->head_b, h->ybuf, c.out_dim * 4, M, c.out_dim * 4, d);
         VCCHK(h, p_gemm(h, g, s));
     }
     const void* y = h->ybuf;

@@ -145,10 +145,19 @@ class SequenceParallel:
             self._alias[key] = t
         return t
 
+    @staticmethod
+    def _on(stream):
+        """Run torch ops on the HIP stream the engine enqueued the surrounding kernels on (its main chain uses the
+        caller's stream, the GeoAdapter chain an engine-owned one)."""
+        if not stream:
+            return torch.cuda.stream(torch.cuda.default_stream())
+        return torch.cuda.stream(torch.cuda.ExternalStream(stream))
+
     def _a2a(self, ctx, send, recv, bytes_per_peer, stream):
         try:
             n = bytes_per_peer * self.world_size
-            all_to_all_bytes(self._buf(send, n), self._buf(recv, n), self.group)
+            with self._on(stream):
+                all_to_all_bytes(self._buf(send, n), self._buf(recv, n), self.group)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             self.error = e
@@ -156,7 +165,8 @@ class SequenceParallel:
 
     def _ag(self, ctx, send, recv, nbytes, stream):
         try:
-            all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self.group)
+            with self._on(stream):
+                all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self.group)
             return 0
         except Exception as e:
             self.error = e
