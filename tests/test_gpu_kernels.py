@@ -202,3 +202,73 @@ def test_rmsnorm_rope(ops, dim, heads):
     ops.rmsnorm_rope_(g3, dev(w), 1e-6)
     assert_bf16_close(g3, O.rms_norm(x.float(), w.float(), 1e-6, mode="bf16").view(B * Lr, dim), ulps=1.01,
                       atol=4e-3, what="rmsnorm")
+
+
+# ------------------------------------------------------------------------ full-size (cfg-3) property tests
+# At BASELINE.json's sizes the CPU oracle is out of reach (44 TFLOP per attention call), so the kernels are checked through
+# size-independent properties of the maths they implement.
+FULL_L, FULL_D, FULL_H = 32760, 5120, 40
+
+
+def test_full_size_attention_key_permutation_and_mask():
+    """softmax(q k^T) v does not depend on the order of the keys; masked keys do not contribute at all."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    from versecrafter_amd import ops
+    B, H, L = 1, 8, FULL_L
+    q = torch.randn(B, L, H, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(B, L, H, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(B, L, H, 128, device="cuda", generator=g).bfloat16()
+    o1 = ops.attention(q, k, v)
+    perm = torch.randperm(L, device="cuda", generator=g)
+    o2 = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous())
+    assert torch.isfinite(o1.float()).all()
+    # different summation order + bf16 P rounding: agree to bf16 output resolution
+    assert rel_l2(o2, o1.float().cpu()) < 4e-3
+    # masking the tail == attending to the truncated key set
+    o3 = ops.attention(q, k, v, k_len=L - 1000)
+    o4 = ops.attention(q, k[:, :L - 1000].contiguous(), v[:, :L - 1000].contiguous())
+    assert torch.equal(o3, o4)
+    # rows are independent: a slice of the queries gives the same rows bit for bit (different workgroup mapping)
+    o5 = ops.attention(q[:, 4096:8192].contiguous(), k, v)
+    assert torch.equal(o5, o1[:, 4096:8192])
+
+
+def test_full_size_gemm_linearity_and_tiles():
+    """C(a1 + a2) = C(a1) + C(a2) without bias (fp32 accumulation, one bf16 rounding), identical across tile configs,
+    row blocks independent of M."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    from versecrafter_amd import ops
+    M, N, K = 2 * FULL_L, FULL_D, FULL_D
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+    # integers keep a1 + a2 exact in bf16
+    a1 = torch.randint(-8, 8, (M, K), device="cuda", generator=g).bfloat16()
+    a2 = torch.randint(-8, 8, (M, K), device="cuda", generator=g).bfloat16()
+    c12 = ops.gemm(a1 + a2, w).float()
+    c1, c2 = ops.gemm(a1, w).float(), ops.gemm(a2, w).float()
+    err = (c12 - (c1 + c2)).abs()
+    assert (err <= 3 * BF16_EPS * (c1.abs() + c2.abs() + c12.abs()) + 1e-2).all()
+    assert torch.equal(ops.gemm(a1, w, tile=1), ops.gemm(a1, w, tile=2))          # same K order in both tile configs
+    assert torch.equal(ops.gemm(a1[5000:9000].contiguous(), w), c1[5000:9000].bfloat16())
+
+
+def test_full_size_row_kernels_invariances():
+    """LayerNorm is invariant to a per-row affine change of its input; RMSNorm to a positive per-row scale (power of two:
+    exact in bf16); RoPE preserves the norm of every (2j, 2j+1) pair."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    from versecrafter_amd import ops
+    M, d = 2 * FULL_L, FULL_D
+    x = torch.randn(M, d, device="cuda", generator=g).bfloat16()
+    mod = torch.zeros(2, 2, d, device="cuda", dtype=torch.bfloat16)
+    y1 = ops.layernorm_modulate(x, mod[:, 0], mod[:, 1], FULL_L)
+    y2 = ops.layernorm_modulate((x.float() * 4).bfloat16(), mod[:, 0], mod[:, 1], FULL_L)
+    # eps = 1e-6 does not scale with the input: equal up to one bf16 rounding
+    assert ((y1.float() - y2.float()).abs() <= 2 * BF16_EPS * y1.float().abs() + 1e-6).all()     # <= 1 bf16 ulp
+    w = torch.ones(d, device="cuda", dtype=torch.bfloat16)
+    r1 = ops.rmsnorm_rope_(x.clone(), w)
+    r2 = ops.rmsnorm_rope_((x.float() * 0.5).bfloat16(), w)
+    assert rel_l2(r2, r1.float().cpu()) < 1e-3          # rsqrt(..) is rounded to bf16 before the multiply: not bit exact
+    tab = ops.rope_table_device(O.rope_table(128), "cuda")
+    r3 = ops.rmsnorm_rope_(x.clone(), w, 1e-6, tab, (21, 30, 52), token_offset=0, rows_per_batch=FULL_L)
+    n1 = r1.float().view(M, d // 2, 2).norm(dim=-1)
+    n3 = r3.float().view(M, d // 2, 2).norm(dim=-1)
+    assert ((n1 - n3).abs() <= 2 * BF16_EPS * n1 + 1e-3).all()

@@ -176,6 +176,16 @@ def test_collective_callbacks_on_rccl_world1():
         assert torch.equal(send, recv)
         y = torch.randn(2, 5, 64, device="cuda").bfloat16()
         assert torch.equal(sp.all_gather_dim1(y), y)
+        # the GeoAdapter chain calls back with an engine-owned (non-default) stream: same collectives on a side stream
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            send2 = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
+            recv2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        side.synchronize()
+        assert sp._a2a(None, send2.data_ptr(), recv2.data_ptr(), n, side.cuda_stream) == 0, sp.error
+        assert sp._ag(None, recv2.data_ptr(), recv.data_ptr(), n, side.cuda_stream) == 0, sp.error
+        side.synchronize()
+        assert torch.equal(send2, recv2) and torch.equal(recv, recv2)
     finally:
         if created:
             dist.destroy_process_group()
