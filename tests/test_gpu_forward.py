@@ -200,3 +200,30 @@ def test_forward_production_widths_vs_oracle(name, dims, grid):
     assert e_hip < 3e-2 and e_hip < 3 * e_ref + 2e-3
     del m
     torch.cuda.empty_cache()
+
+
+def test_cfg3_full_model_properties():
+    """The bench workload itself (Wan2.1-14B + GeoAdapter, 81f 480x832, B=2): finite, deterministic, and the two CFG
+    halves are computed independently (swapping them swaps the outputs bit for bit)."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16,
+                                          dim=5120, ffn_dim=13824, num_heads=40, num_layers=40)
+    m.init_weights(zero_init_outputs=False)
+    T, h, w = 21, 60, 104
+    g = torch.Generator().manual_seed(2025)
+    x = torch.randn(2, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    geo = torch.randn(2, 128, T, h, w, generator=g).to(dev, torch.bfloat16)
+    ctx = [torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16)]
+    t = torch.tensor([900.0, 900.0], device=dev)
+    L = T * (h // 2) * (w // 2)
+    a = m(x, t, geo, ctx, L)
+    b = m(x, t, geo, ctx, L)
+    c = m(x.flip(0), t, geo.flip(0), ctx[::-1], L)
+    torch.cuda.synchronize()
+    assert a.shape == (2, 16, T, h, w) and torch.isfinite(a.float()).all() and a.float().abs().max() > 0
+    assert torch.equal(a, b)
+    assert torch.equal(c, a.flip(0))
+    del m
+    torch.cuda.empty_cache()

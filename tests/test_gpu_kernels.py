@@ -272,3 +272,20 @@ def test_full_size_row_kernels_invariances():
     n1 = r1.float().view(M, d // 2, 2).norm(dim=-1)
     n3 = r3.float().view(M, d // 2, 2).norm(dim=-1)
     assert ((n1 - n3).abs() <= 2 * BF16_EPS * n1 + 1e-3).all()
+
+
+def test_config4_sequence_length_attention():
+    """BASELINE.json config 4 (81 frames 720p): 75600 tokens.  Same properties at the long-sequence stress length, on the
+    packed q|k|v layout the engine uses (row stride 3*5120 elements: byte offsets beyond 2^31)."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    from versecrafter_amd import ops
+    L, H, d = 75600, 40, 5120
+    qkv = torch.randn(1, L, 3 * d, device="cuda", generator=g).bfloat16()
+    q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128))[:, :, 37:39] for i in range(3))   # heads 37, 38
+    o1 = ops.attention(q, k, v, k_len=L)
+    assert torch.isfinite(o1.float()).all()
+    o2 = ops.attention(q[:, 70000:].contiguous(), k.contiguous(), v.contiguous())     # contiguous copies, row slice
+    assert torch.equal(o2, o1[:, 70000:])
+    perm = torch.randperm(L, device="cuda", generator=g)
+    o3 = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous())
+    assert rel_l2(o3, o1.float().cpu()) < 4e-3
