@@ -53,7 +53,7 @@ def rel_l2(got, want):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 768, 1024), (37, 64, 64), (513, 256, 128)])
 def test_gemm_bias(ops, tile, M, N, K):
     rs = np.random.RandomState(M + N + K)
@@ -73,7 +73,7 @@ def test_gemm_asymmetric_identity(ops):
     assert torch.equal(got.float().cpu(), w.float().t())
 
 
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 def test_gemm_epilogues(ops, tile):
     rs = np.random.RandomState(5)
     B, Lr, N, K = 2, 150, 512, 256

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvcengine.so")
+LIB_PATH = os.environ.get("VC_ENGINE_LIB", os.path.join(_HERE, "libvcengine.so"))   # override: A/B of two builds
 
 VC_OK = 0
 VC_E_INVALID, VC_E_HIP, VC_E_STATE, VC_E_NOMEM, VC_E_UNSUPPORTED = -1, -2, -3, -4, -5

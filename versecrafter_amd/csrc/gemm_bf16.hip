@@ -47,6 +47,18 @@ VC_DEVICE void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset; inline asm keeps it out of hipcc's
+// vmcnt bookkeeping (the kernel waits for it itself, right before the barrier that publishes the stage)
+VC_DEVICE void glds16_sbase(unsigned voff, const void* sbase, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
 template <class Cfg>
 VC_DEVICE void stage_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W, int64_t ldw,
                           int m0, int n0, int M, int N, int k0, char* buf, int tid, int wave) {
@@ -70,7 +82,7 @@ VC_DEVICE void stage_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     }
 }
 
-template <class Cfg>
+template <class Cfg, bool SB>
 __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MI = Cfg::MI, NI = Cfg::NI;
@@ -104,7 +116,54 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / Cfg::BK;
-    stage_tile<Cfg>(A, p.lda, W, p.ldw, m0, n0, p.M, p.N, 0, smem, tid, wave);
+    // SB: 32-bit per-lane byte offsets computed once + a scalar base advanced per K-step
+    unsigned aoff[Cfg::A_LOADS], boff[Cfg::B_LOADS];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_t*)smem;
+    if (SB) {
+#pragma unroll
+        for (int i = 0; i < Cfg::A_LOADS; ++i) {
+            const int q = i * Cfg::THREADS + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int gr = m0 + row;
+            gr = gr < p.M ? gr : p.M - 1;
+            aoff[i] = (unsigned)(((int64_t)gr * p.lda + c * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::B_LOADS; ++i) {
+            const int q = i * Cfg::THREADS + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int gr = n0 + row;
+            gr = gr < p.N ? gr : p.N - 1;
+            boff[i] = (unsigned)(((int64_t)gr * p.ldw + c * 8) * 2);
+        }
+    }
+    // all 8 pieces of a K-step in ONE asm statement: M0 (LDS destination of the wave) is saved / restored once and
+    // stepped by 8 KiB between pieces (piece i of a wave lands at stage + wave*1 KiB + i*8 KiB; the W tile follows A)
+    static_assert(!SB || (Cfg::A_LOADS == 4 && Cfg::B_LOADS == 4 && Cfg::THREADS * 16 == 0x2000),
+                  "stage_sb assumes 256x256x64 / 512 threads");
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    auto stage_sb = [&](int kstep) {
+        const unsigned start = lds_wave + (kstep & 1) * Cfg::STAGE_BYTES;
+        const bf16_t* ab = A + kstep * Cfg::BK;
+        const bf16_t* wb = W + kstep * Cfg::BK;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[start]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a0], %[ab]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a1], %[ab]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a2], %[ab]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a3], %[ab]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b0], %[wb]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b1], %[wb]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b2], %[wb]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b3], %[wb]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [start] "s"(start), [ab] "s"(ab), [wb] "s"(wb), [a0] "v"(aoff[0]), [a1] "v"(aoff[1]), [a2] "v"(aoff[2]),
+              [a3] "v"(aoff[Cfg::A_LOADS - 1]), [b0] "v"(boff[0]), [b1] "v"(boff[1]), [b2] "v"(boff[2]),
+              [b3] "v"(boff[Cfg::B_LOADS - 1])
+            : "memory", "scc");
+    };
+    if (SB) stage_sb(0);
+    else stage_tile<Cfg>(A, p.lda, W, p.ldw, m0, n0, p.M, p.N, 0, smem, tid, wave);
 
     // per-lane fragment addressing (swizzled chunk for ks = 0, 1)
     const int frow = lane & 15;
@@ -118,9 +177,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // tile kt has landed for every wave; every wave is done reading the other buffer
         char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
-        if (kt + 1 < nk)
-            stage_tile<Cfg>(A, p.lda, W, p.ldw, m0, n0, p.M, p.N, (kt + 1) * Cfg::BK,
-                            smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES, tid, wave);
+        if (kt + 1 < nk) {
+            if (SB) stage_sb(kt + 1);
+            else stage_tile<Cfg>(A, p.lda, W, p.ldw, m0, n0, p.M, p.N, (kt + 1) * Cfg::BK,
+                                 smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES, tid, wave);
+        }
         // all fragment reads of this K-step first (2 k-substeps x (MI + NI) ds_read_b128), then the MFMA chain:
         // the LDS latency is paid once per K-step instead of once per group of MFMAs
         bf16x8 af[2][MI], bfr[2][NI];
@@ -193,11 +254,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
     }
 }
 
-template <class Cfg>
+template <class Cfg, bool SB = false>
 int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Cfg>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Cfg, SB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return VC_E_HIP;
         attr_set = true;
@@ -206,14 +267,14 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
     const int nTm = (p.M + Cfg::BM - 1) / Cfg::BM, nTn = ng * ((p.N + Cfg::BN - 1) / Cfg::BN);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(gemm_bf16_kernel<Cfg>, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, p, nTm, nTn,
+    hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, SB>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, p, nTm, nTn,
                        ntiles);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 
 }  // namespace
 
-int vc_gemm_tile_override = 0;   // 0 auto, 1 -> 128x128, 2 -> 256x256 (tests / tuning)
+int vc_gemm_tile_override = 0;   // 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses (tests)
 
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
@@ -228,6 +289,9 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     bool big = (p.M >= 1024 && p.N >= 256);
     if (vc_gemm_tile_override == 1) big = false;
     if (vc_gemm_tile_override == 2) big = true;
+    // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
+    const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
+    if (big && fits32 && vc_gemm_tile_override != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);
     if (big) return launch_cfg<GemmCfg<256, 256, 2, 4>>(p, stream);
     return launch_cfg<GemmCfg<128, 128, 2, 2>>(p, stream);
 }
