@@ -115,6 +115,46 @@ def test_gemm_strided_output(ops):
     assert_bf16_close(out, want, ulps=1.01, atol=2e-3, what="strided")
 
 
+def _padded_rows(t, mult=256):
+    """Device copy of t [M, K] inside a buffer whose rows run to the next multiple of `mult` (the ping-pong kernel
+    reads, never stores, those rows); the pad is filled with NaN to prove it cannot leak into stored rows."""
+    M, K = t.shape
+    buf = torch.full(((M + mult - 1) // mult * mult, K), float("nan"), dtype=torch.bfloat16, device="cuda")
+    buf[:M] = t.to("cuda")
+    return buf[:M]
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 128), (1100, 512, 1024), (2047, 768, 384), (4096, 1280, 2560)])
+def test_gemm_pingpong_bias(ops, M, N, K):
+    """tile=4: the 8-phase ping-pong kernel (production path for the engine's big GEMMs) against the oracle and,
+    bit for bit, against the 2-stage kernel (same K order => same fp32 sums)."""
+    rs = np.random.RandomState(M + N + K)
+    a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
+    ap = _padded_rows(a)
+    got = ops.gemm(ap, dev(w), dev(b), tile=4)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, O.linear(a.float(), w.float(), b.float()), ulps=1.01, atol=2e-3, what="pingpong bias")
+    assert torch.equal(got, ops.gemm(ap, dev(w), dev(b), tile=2))
+
+
+def test_gemm_pingpong_epilogues_and_race_screen(ops):
+    rs = np.random.RandomState(11)
+    B, Lr, N, K = 2, 1000, 512, 640
+    M = B * Lr
+    a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
+    resid, hint, gate = bf(rs_randn(rs, M, N)), bf(rs_randn(rs, M, N)), bf(rs_randn(rs, B, N))
+    ap = _padded_rows(a)
+    kw = [dict(epilogue=ops.EPI_BIAS_GELU),
+          dict(epilogue=ops.EPI_BIAS_RESID, resid=dev(resid)),
+          dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=dev(resid), gate=dev(gate), rows_per_batch=Lr),
+          dict(epilogue=ops.EPI_BIAS_GATE_RESID, resid=dev(resid), gate=dev(gate), rows_per_batch=Lr, hint=dev(hint),
+               hint_scale=0.6)]
+    for k in kw:
+        want = ops.gemm(ap, dev(w), dev(b), tile=2, **k)       # tile 2 is checked against the oracle above
+        for _ in range(25):                                    # staging races show up as rare wrong tiles
+            assert torch.equal(ops.gemm(ap, dev(w), dev(b), tile=4, **k), want)
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,Lq,Lk,k_len", [(2, 2, 200, 200, 150), (1, 3, 130, 1000, 0), (2, 1, 72, 48, 0),
                                              (1, 2, 129, 64, 64), (1, 1, 64, 520, 513)])

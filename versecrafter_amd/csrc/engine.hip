@@ -235,6 +235,7 @@ VcGemmParams gemm(const void* A, int64_t lda, const void* Wt, const void* bias, 
     memset(&p, 0, sizeof p);
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.epilogue = epi; p.valid_rows = -1;
+    p.a_rows_padded = 1;      // every A operand of the engine lives in the arena, which ends in a 256-row pad (vc_prepare_video)
     return p;
 }
 
@@ -569,6 +570,13 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
                   o_fe = take((int64_t)B * d * 4), o_fe0 = take((int64_t)B * 6 * d * 4);
     const int64_t kvb = (int64_t)B * TL * d * 2;
     const int64_t o_kv = take(2 * kvb * nblk);
+    // tail pad: the ping-pong GEMM reads (never stores) A rows up to the next multiple of 256 past M
+    {
+        int64_t widest = f > 3 * d ? f : 3 * d;
+        if (kmax > widest) widest = kmax;
+        if (c.text_dim > widest) widest = c.text_dim;
+        (void)take(256 * widest * 2);
+    }
     if (hipMalloc(&h->arena, off) != hipSuccess) {
         (void)hipGetLastError();
         h->arena = nullptr;
@@ -790,6 +798,7 @@ int vc_op_gemm_bf16(const void* A, int64_t lda, const void* Wt, int64_t ldw, voi
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
     p.epilogue = epilogue; p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_bstride = gate_bstride;
     p.rows_per_batch = rows_per_batch; p.hint = hint; p.ldh = ldh; p.hint_scale = hint_scale; p.valid_rows = -1;
+    p.a_rows_padded = tile == 4;     // tile 4 (tests / tuning): the caller promises A is readable up to the next 256 rows
     const int prev = vc_gemm_tile_override;
     vc_gemm_tile_override = tile;
     const int r = vc_launch_gemm(p, (hipStream_t)stream);

@@ -254,6 +254,243 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
     }
 }
 
+// =====================================================================================================
+// Ping-pong kernel (production kernel for the engine's large GEMMs): 256x256x64 tile, 8 waves (2 x 4, 128x64 each),
+// 2 LDS stages of 64 KiB.  The two waves of a SIMD (wave w and w+4: groups G0 = rows 0-127, G1 = rows 128-255) run the
+// same program one barrier apart, so that at any time one of them is in a 16-MFMA section (one quadrant of its output
+// x K=64) and the other in a "load" section (4-12 ds_read_b128 fragment reads + the 2 LDS-DMA pieces that are its share
+// of one half-tile of a later K-tile).  Eight phases = two K-tiles per loop trip; per phase
+//     reads ; DMA ; [lgkmcnt] ; barrier ; MFMA x16 ; barrier
+// K-tile image in LDS (per stage): [A half0 | A half1 | B half0 | B half1], 16 KiB each, where half h of A holds, for
+// both wave groups, the 64 rows each wave uses in its quadrants h (and likewise 32-row slices of B for the 4 wave
+// columns): a half is dead once the phase that reads it has passed, which is what lets its successor (K-tile + 2) be
+// staged while the K-tile is still being computed:
+//     phase 1: reads B0,A0 of E   stages Ah1 of O      phase 5: reads B0,A0 of O   stages Ah1 of E'
+//     phase 2: reads B1           stages Bh0 of E'     phase 6: reads B1           stages Bh0 of O'
+//     phase 3: reads A1           stages Ah0 of E'     phase 7: reads A1           stages Ah0 of O'
+//     phase 4: -                  stages Bh1 of E'     phase 8: -                  stages Bh1 of O'
+//              vmcnt(6): O landed                               vmcnt(6): E' landed
+// (E/O = K-tile in the even/odd stage, ' = two K-tiles later).  WAR: a half is restaged two phases after its last
+// read, except Bh0 (one phase; its 4 reads are issued first in phases 1/5 and retired by lgkmcnt(8) before the
+// barrier).  RAW: the counted vmcnt sits before a barrier that every reader passes before its first read.
+// Rows past M are read (never stored): the caller guarantees they are readable (a_rows_padded / M % 256 == 0).
+// Past the last K-tile the staging re-reads the last K-tile into a dead stage (keeps vmcnt counts uniform).
+// =====================================================================================================
+__global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per_xcd = gridDim.x >> 3;
+    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (id >= ntiles) return;
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * nTn;
+    const int group = id / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(nTm - first_m, GROUP_M);
+    const int tm = first_m + (id % width) % gsz;
+    int tn = (id % width) / gsz;
+    const int nTn1 = p.ngroups > 1 ? nTn / p.ngroups : nTn;
+    const int grp = tn / nTn1;
+    tn -= grp * nTn1;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    auto uniform_ptr = [](const char* q) {     // force a wave-uniform address into an SGPR pair
+        const uint64_t u = (uint64_t)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
+    const int64_t lda2 = p.lda * 2, ldw2 = p.ldw * 2;      // row pitches in bytes
+    // staging: per half-tile a wave moves pieces `wave` and `wave + 8` (8 LDS rows of 128 B each); both have the
+    // parity of `wave`, so the lane's swizzled chunk is one constant
+    const int r8 = lane >> 3;
+    const int chunk = (lane & 7) ^ ((r8 >> 1) + 4 * (wave & 1));
+    const unsigned voff_a = (unsigned)(r8 * lda2 + chunk * 16);
+    const unsigned voff_w = (unsigned)(r8 * ldw2 + chunk * 16);
+    // first source row of piece `wave` in half 0:  A: 8*wave (group 0; piece wave+8 = group 1, +128 rows)
+    //                                              W: wave column wave>>2, 8*(wave&3) (piece wave+8: column +2, +128 rows)
+    const char* a_src = uniform_ptr((const char*)p.A + ((int64_t)m0 + 8 * wave) * lda2);
+    const char* w_src = uniform_ptr((const char*)(grp == 0 ? p.W : p.Wg[grp - 1]) +
+                                    ((int64_t)n0 + (wave >> 2) * 64 + (wave & 3) * 8) * ldw2);
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)smem + wave * 1024);
+    const int nk = p.K >> 6;
+
+    // region: 0 Ah0, 1 Ah1, 2 Bh0, 3 Bh1
+    auto stage_half = [&](int stage, int region, int kt) {
+        kt = kt < nk ? kt : nk - 1;
+        const bool isA = region < 2;
+        const int hh = region & 1;
+        const char* s0 = isA ? a_src + (int64_t)hh * 64 * lda2 : w_src + (int64_t)hh * 32 * ldw2;
+        s0 += (int64_t)kt * 128;
+        const char* s1 = s0 + 128 * (isA ? lda2 : ldw2);
+        const unsigned d0 = lds_wave + stage * 65536 + region * 16384;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[s0]\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[s1]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [d0] "s"(d0), [v] "v"(isA ? voff_a : voff_w), [s0] "s"(s0), [s1] "s"(s1)
+            : "memory", "scc");
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment reads: LDS row (within a half) of A = wr*64 + i*16 + frow, of B = wc*32 + j*16 + frow
+    const int frow = lane & 15;
+    const int sw = (lane >> 1) & 7;
+    const int pc0 = ((lane >> 4) ^ sw) << 4, pc1 = ((4 + (lane >> 4)) ^ sw) << 4;
+    const char* a_rd = smem + (wr * 64 + frow) * 128;
+    const char* b_rd = smem + 32768 + (wc * 32 + frow) * 128;
+    bf16x8 af[4][2], bf[2][2][2];       // af[i][ks] (half in use), bf[half][j][ks]
+    auto read_a = [&](int stage, int hh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc0);
+            af[i][1] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc1);
+        }
+    };
+    auto read_b = [&](int stage, int hh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[hh][j][0] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
+            bf[hh][j][1] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
+        }
+    };
+    auto mma = [&](int ah, int bh) {   // quadrant (A half ah, B half bh) x K=64: 16 MFMA
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ah * 4 + i][bh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[bh][j][ks], af[i][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define VC_PP_BARRIER()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VC_PP_WAIT(str)  do { __builtin_amdgcn_sched_barrier(0); asm volatile(str ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    // ---- prologue: K-tile 0 complete, K-tile 1 minus its Ah1 in flight ----
+    stage_half(0, 2, 0); stage_half(0, 0, 0); stage_half(0, 3, 0); stage_half(0, 1, 0);
+    stage_half(1, 2, 1); stage_half(1, 0, 1); stage_half(1, 3, 1);
+    VC_PP_WAIT("s_waitcnt vmcnt(6)");
+    VC_PP_BARRIER();
+    if (wr == 1) VC_PP_BARRIER();          // group 1 runs one barrier behind group 0
+
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {     // st = 0: K-tile kt (even stage), st = 1: K-tile kt+1 (odd stage)
+            // phase 1 / 5
+            read_b(st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(st, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_half(st ^ 1, 1, kt + 1 + st);                 // Ah1 of the other stage's next K-tile
+            VC_PP_WAIT("s_waitcnt lgkmcnt(8)");                  // the 4 B reads are done: Bh0 may be restaged next phase
+            VC_PP_BARRIER();
+            mma(0, 0);
+            VC_PP_BARRIER();
+            // phase 2 / 6
+            read_b(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_half(st, 2, kt + 2 + st);                      // Bh0 of this stage's next K-tile
+            VC_PP_BARRIER();
+            mma(0, 1);
+            VC_PP_BARRIER();
+            // phase 3 / 7
+            read_a(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_half(st, 0, kt + 2 + st);                      // Ah0
+            VC_PP_BARRIER();
+            mma(1, 1);
+            VC_PP_BARRIER();
+            // phase 4 / 8
+            stage_half(st, 3, kt + 2 + st);                      // Bh1
+            VC_PP_WAIT("s_waitcnt vmcnt(6)");                    // the other stage's K-tile has landed (this wave's pieces)
+            VC_PP_BARRIER();
+            mma(1, 0);
+            VC_PP_BARRIER();
+        }
+    }
+    if (wr == 0) VC_PP_BARRIER();          // equalise the barrier count
+    VC_PP_WAIT("s_waitcnt vmcnt(0)");      // nothing may still be landing in LDS when the workgroup retires
+#undef VC_PP_BARRIER
+#undef VC_PP_WAIT
+
+    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
+    const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
+    const bf16_t* resid = (const bf16_t*)p.resid;
+    const bf16_t* gate = (const bf16_t*)p.gate;
+    const bf16_t* hint = (const bf16_t*)p.hint;
+    bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / rpb;
+        const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (bias) {
+                float bb[4];
+                unpack4(*(const uint2*)(bias + n), bb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (p.epilogue == VC_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
+            } else if (p.epilogue == VC_EPI_BIAS_RESID) {
+                float r[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+            } else if (p.epilogue == VC_EPI_BIAS_GATE_RESID) {
+                float r[4], gg[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+                unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), gg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * gg[e]);
+                if (hint) {
+                    float hv[4];
+                    unpack4(*(const uint2*)(hint + (int64_t)m * p.ldh + n), hv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(hv[e] * p.hint_scale);
+                }
+            }
+            if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
+            *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
+        }
+    }
+}
+
+int launch_pp(const VcGemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 65536;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return VC_E_HIP;
+        attr_set = true;
+    }
+    const int ng = p.ngroups > 1 ? p.ngroups : 1;
+    const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
+    const int ntiles = nTm * nTn;
+    const int grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
 template <class Cfg, bool SB = false>
 int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
@@ -274,7 +511,7 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int vc_gemm_tile_override = 0;   // 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses (tests)
+int vc_gemm_tile_override = 0;   // 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel (tests)
 
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
@@ -289,6 +526,11 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     bool big = (p.M >= 1024 && p.N >= 256);
     if (vc_gemm_tile_override == 1) big = false;
     if (vc_gemm_tile_override == 2) big = true;
+    // every tile row readable (M a multiple of 256 or padded buffers), N % 256 == 0, K % 128 == 0: ping-pong kernel
+    const bool rows_ok = (p.M % 256 == 0) || p.a_rows_padded;
+    if (big && rows_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
+        (vc_gemm_tile_override == 0 || vc_gemm_tile_override == 4))
+        return launch_pp(p, stream);
     // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
     if (big && fits32 && vc_gemm_tile_override != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);
