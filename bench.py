@@ -198,7 +198,7 @@ def main():
             dom = max(("attn_self", "gemm"), key=lambda k: prof[k]["ms"])
             v = prof[dom]
             ach = v["flops"] / (v["ms"] / 1e3) / 1e12
-            kname = {"attn_self": "attn_fwd_pipe_kernel", "gemm": "gemm_bf16_kernel"}[dom]
+            kname = {"attn_self": "attn_fwd_pipe_kernel", "gemm": "gemm_pp_kernel"}[dom]
             traffic = None      # HBM bytes per launch come from the committed PMC passes (profiles/traffic.json), not live
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
