@@ -107,24 +107,66 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     const int nt = (k_len + KT - 1) / KT;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
     constexpr int RPW = KT / NW;                          // tile rows staged per wave (16 or 8)
-    const int row_in_tile0 = wave * RPW + (lane >> 4);    // + 4*i
     const int pc = lane & 15;
 
-    // stage K(t) / V(t): 4 wave-instructions each; rows clamped to Lk-1 (only the last tile can exceed)
-    auto stage = [&](int t, bool do_k, bool do_v, int kst, int vst) {
+    // stage K(t) / V(t): RPW/4 wave-instructions (pieces of 4 tile rows) each.  A wave's pieces are 16 rows apart, so the
+    // swizzled chunk of a lane is the same in all of them: ONE per-lane byte offset per operand; the tile and the piece
+    // are selected through the wave-uniform 64-bit base (SALU only -- no vector instruction per piece).  Tiles are
+    // staged in order (K: 0, 1, 2, ...; V: 0, 1, ...), so the byte offset of a tile's first key is carried in scalar
+    // registers (StreamPos).  Segmented token axis (Ulysses receive layout, segments of seg_len >= 64 keys): a tile
+    // straddles at most one segment boundary; pieces past it take the next segment's base, the piece on it and the last,
+    // partial tile (and seg_len < 64) go through the generic per-row path with rows clamped to Lk-1.
+    struct StreamPos { unsigned A; int w0; };          // A: byte offset of the tile's first key; w0: its index in its segment
+    const unsigned k_ts2 = (unsigned)(p.k_ts * 2), v_ts2 = (unsigned)(p.v_ts * 2);
+    const unsigned k_jump = SEG ? (unsigned)((p.k_ss - (int64_t)p.seg_len * p.k_ts) * 2) : 0u;
+    const unsigned v_jump = SEG ? (unsigned)((p.v_ss - (int64_t)p.seg_len * p.v_ts) * 2) : 0u;
+    const bool fast_ok = !SEG || p.seg_len >= KT;
+    const int qbase = __builtin_amdgcn_readfirstlane(NW == 8 ? (wave & 3) + 8 * (wave >> 2) : wave);   // pieces qbase + 4j
+    const int lrow = 4 * qbase + (lane >> 4);          // this lane's tile row in piece j = 0 (piece j: + 16 j)
+    const unsigned klane = (unsigned)lrow * k_ts2 + ((pc ^ (lrow & 15)) << 4);
+    const unsigned vlane = (unsigned)lrow * v_ts2 + ((pc ^ v_swz(lrow)) << 4);
+    auto stage_one = [&](int t, bool is_k, int st, StreamPos& sp) {
+        const unsigned ts2 = is_k ? k_ts2 : v_ts2, jump = is_k ? k_jump : v_jump;
+        const char* base = (const char*)(is_k ? kp : vp);
+        const unsigned dst = lds0 + (is_k ? P_KST : P_VST) + st * TILE_BYTES + qbase * 1024;
+        const int bnd = SEG ? p.seg_len - sp.w0 : KT;              // first tile row that belongs to the next segment
+        bool fast = fast_ok && (t + 1) * KT <= p.Lk;
+        if (SEG) {                                                 // a piece ON the boundary needs per-row addresses
 #pragma unroll
-        for (int i = 0; i < RPW / 4; ++i) {
-            const int row = row_in_tile0 + 4 * i;
-            int key = t * KT + row;
-            key = key < p.Lk ? key : p.Lk - 1;
-            const int row0 = __builtin_amdgcn_readfirstlane(wave * RPW + 4 * i);
-            if (do_k)
-                glds16_s(row_byte_off<SEG>(key, p.k_ts, p.seg_len, p.k_ss) + ((pc ^ (row & 15)) << 4), kp,
-                         __builtin_amdgcn_readfirstlane(lds0 + P_KST + kst * TILE_BYTES + row0 * 256));
-            if (do_v)
-                glds16_s(row_byte_off<SEG>(key, p.v_ts, p.seg_len, p.v_ss) + ((pc ^ v_swz(row)) << 4), vp,
-                         __builtin_amdgcn_readfirstlane(lds0 + P_VST + vst * TILE_BYTES + row0 * 256));
+            for (int j = 0; j < RPW / 4; ++j) {
+                const int row0 = 4 * qbase + 16 * j;
+                fast = fast && !(bnd > row0 && bnd < row0 + 4);
+            }
         }
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < RPW / 4; ++j) {
+                const int row0 = 4 * qbase + 16 * j;               // first tile row of the piece (wave-uniform)
+                unsigned a = sp.A + (unsigned)(16 * j) * ts2;
+                if (SEG) a += row0 >= bnd ? jump : 0u;
+                glds16_s(is_k ? klane : vlane, base + a, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPW / 4; ++j) {
+                const int row = lrow + 16 * j;
+                int key = t * KT + row;
+                key = key < p.Lk ? key : p.Lk - 1;
+                const unsigned sw = is_k ? (unsigned)(row & 15) : (unsigned)v_swz(row);
+                glds16_s(row_byte_off<SEG>(key, is_k ? p.k_ts : p.v_ts, p.seg_len, is_k ? p.k_ss : p.v_ss) + ((pc ^ sw) << 4),
+                         base, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+            }
+        }
+        sp.A += (unsigned)KT * ts2;
+        if (SEG && fast_ok) {
+            sp.w0 += KT;
+            if (sp.w0 >= p.seg_len) { sp.w0 -= p.seg_len; sp.A += jump; }
+        }
+    };
+    StreamPos kpos{0u, 0}, vpos{0u, 0};
+    auto stage = [&](int t, bool do_k, bool do_v, int kst, int vst) {
+        if (do_k) stage_one(t, true, kst, kpos);
+        if (do_v) stage_one(t, false, vst, vpos);
     };
 
     stage(0, true, true, 0, 0);

@@ -545,7 +545,10 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return o; };
     const int64_t md = (int64_t)M * d * 2;
-    h->dual = (P > 1) || (getenv("VC_DUAL_LANE") && atoi(getenv("VC_DUAL_LANE")) == 1);
+    {   // default: dual lane (adapter chain on its own stream) only under sequence parallelism; VC_DUAL_LANE=0/1 forces it
+        const char* dl = getenv("VC_DUAL_LANE");
+        h->dual = dl ? atoi(dl) == 1 : (P > 1);
+    }
     const int nlanes = h->dual ? 2 : 1;
     const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md), o_x0 = take(md), o_resid = take(md);
     int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2];
