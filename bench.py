@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--num_inference_steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--teacache-steps", type=int, default=0,
+                    help="also time N sampler steps from step 0 with TeaCache on (CLI defaults: threshold 0.10, skip-start 5) "
+                         "and report them as a separate 'teacache_on' object; 0 = off (the headline metric is TeaCache-off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,6 +169,26 @@ def main():
         prof = model.profile_read()
         model.profile_enable(False)
     finite = bool(torch.isfinite(lat.float()).all().item())
+    tea = None
+    if args.teacache_steps > 0:
+        # TeaCache-on is a separate line.  With random weights the gate's statistics are not those of the
+        # released checkpoint -- the count of skipped steps is reported next to the rate.
+        coeff_14b = [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02]   # CLI.py:305-313
+        model.enable_teacache(coeff_14b, args.num_inference_steps, 0.10, num_skip_start_steps=5, offload=False)
+        scheduler.set_timesteps(args.num_inference_steps, device=dev, shift=16)
+        n = min(args.teacache_steps, args.num_inference_steps)
+        skipped = 0
+        barrier()
+        t1 = time.perf_counter()
+        lt = latents
+        for i in range(n):
+            lt = pipe.denoise_step(i, ts[i], lt, embeds, geoada_in, seq_len, True, 1.0)
+            skipped += 0 if model.should_calc else 1
+        barrier()
+        el = time.perf_counter() - t1
+        model.disable_teacache()
+        tea = {"value": n / el, "unit": "denoise-steps/s", "steps": n, "skipped_steps": skipped, "threshold": 0.10,
+               "num_skip_start_steps": 5, "note": "random weights: gate statistics differ from the released checkpoint"}
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -211,6 +234,8 @@ def main():
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
             out["breakdown"] = bd
+        if tea is not None:
+            out["teacache_on"] = tea
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mk, f_step)
         print(json.dumps(out), flush=True)

@@ -129,6 +129,12 @@ int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batc
 int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps, const void* table,
                        const int32_t* grid5, void* stream);
 
+/* Control-map front-end of one sample (PIPE.py:440-488, geoada_encode_masks + geoada_latent, ref_images = None):
+ * out [128,T,h,w] bf16 = concat( z [64,T,h,w] bf16 ,  nearest-exact frame resize of the 8x8 pixel-unshuffle of
+ * mask[0] [F,H,W] (bf16, or fp32 when mask_is_f32) ).  T = (F+3)/4, h = 2*(H/16) = H/8, w = W/8. */
+int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F, int H,
+                         int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

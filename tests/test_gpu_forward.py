@@ -136,6 +136,32 @@ def test_pipeline_three_step_trace_vs_oracle(model, fwd):
     assert got.shape == (1, 16, T, h, w) and r < 6e-2
 
 
+def test_pipeline_mask_video_front_end_equals_mask_latents(model, fwd):
+    """__call__(mask_video=...) builds geoada_context with the HIP front-end kernel (PIPE.py:440-488); the result must be
+    bit-identical to feeding mask_latents produced by the host restatement of geoada_encode_masks."""
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.pipeline.pipeline_wan_versecrafter import geoada_encode_masks
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    F_, H_, W_ = 9, 64, 96
+    T, h, w = 3, 8, 12
+    g = torch.Generator().manual_seed(6)
+    geo_lat = torch.randn(64, T, h, w, generator=g).bfloat16()
+    mask_video = (torch.rand(1, 1, F_, H_, W_, generator=g) < 0.5).float()
+    mask_video[:, :, 0] = 0                                                        # CLI.py:395
+    pe, ne = torch.randn(33, 64, generator=g).bfloat16(), torch.randn(20, 64, generator=g).bfloat16()
+    lat0 = torch.randn(1, 16, T, h, w, generator=g).bfloat16()
+    outs = []
+    for use_video in (True, False):
+        pipe = WanVerseCrafterPipeline(transformer=model, scheduler=FlowUniPCMultistepScheduler(shift=1))
+        kw = dict(mask_video=mask_video.cuda()) if use_video else dict(
+            mask_latents=[m.to(torch.bfloat16).cuda() for m in geoada_encode_masks(torch.tile(mask_video, [1, 3, 1, 1, 1]))])
+        outs.append(pipe(prompt_embeds=[pe.cuda()], negative_prompt_embeds=[ne.cuda()], height=H_, width=W_,
+                         geoada_latents=[geo_lat.cuda()], num_inference_steps=2, guidance_scale=5.0, shift=16,
+                         latents=lat0.clone().cuda(), output_type="latent", **kw).videos)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+
+
 def test_cli_runs_end_to_end(tmp_path):
     """inference/versecrafter_inference.py with the reference's flags, synthetic inputs, tiny random model."""
     import subprocess

@@ -155,6 +155,32 @@ def test_gemm_pingpong_epilogues_and_race_screen(ops):
             assert torch.equal(ops.gemm(ap, dev(w), dev(b), tile=4, **k), want)
 
 
+# ------------------------------------------------------------------------------- control-map front-end
+@pytest.mark.parametrize("F,H,W", [(9, 64, 96), (81, 96, 160), (49, 32, 64), (1, 32, 32), (6, 48, 80)])
+@pytest.mark.parametrize("mdtype", [torch.bfloat16, torch.float32])
+def test_geoada_context_matches_oracle_bitwise(ops, F, H, W, mdtype):
+    """PIPE.py:440-488 (mask pixel-unshuffle, nearest-exact frame resize, channel concat): pure data movement, so the
+    HIP kernel must reproduce the oracle's restatement bit for bit (incl. the non-integer frame ratios 81->21, 49->13)."""
+    g = torch.Generator().manual_seed(F * 1000 + H + W)
+    T, h, w = (F + 3) // 4, H // 8, W // 8
+    z = bf(torch.randn(64, T, h, w, generator=g))
+    mask = (torch.rand(3, F, H, W, generator=g) < 0.5).float() * torch.rand(3, F, H, W, generator=g)   # not only {0,1}
+    mask = mask.to(mdtype)
+    want = torch.cat([z, O.geoada_encode_masks(mask.float()).to(torch.bfloat16)], 0)
+    got = ops.geoada_context(dev(z), dev(mask))
+    assert got.shape == (128, T, h, w) and torch.equal(got.cpu(), want)
+
+
+def test_geoada_context_rejects_mismatched_shapes(ops):
+    z = torch.zeros(64, 3, 8, 12, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        ops.geoada_context(z, torch.zeros(1, 9, 64, 100, dtype=torch.bfloat16, device="cuda"))   # W != 8 w
+    with pytest.raises(ValueError):
+        ops.geoada_context(z, torch.zeros(1, 13, 64, 96, dtype=torch.bfloat16, device="cuda"))   # (13+3)//4 != 3
+    with pytest.raises(RuntimeError):
+        ops.geoada_context(z, torch.zeros(1, 9, 64, 96, dtype=torch.bfloat16))                    # CPU tensor
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,Lq,Lk,k_len", [(2, 2, 200, 200, 150), (1, 3, 130, 1000, 0), (2, 1, 72, 48, 0),
                                              (1, 2, 129, 64, 64), (1, 1, 64, 520, 513)])

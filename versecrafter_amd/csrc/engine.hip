@@ -839,4 +839,12 @@ int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, fl
                                   (hipStream_t)stream);
 }
 
+int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F, int H,
+                         int W, void* stream) {
+    // PIPE.py:459-466: the latent grid is 2*(H//16) x 2*(W//16) and mask.view(depth, h, 8, w, 8) must cover the frame
+    if (H <= 0 || W <= 0 || h != 2 * (H / 16) || w != 2 * (W / 16) || H != 8 * h || W != 8 * w) return VC_E_INVALID;
+    if (T != (F + 3) / 4) return VC_E_INVALID;                 // new_depth = (depth + 3) // 4
+    return vc_launch_geoada_context(z, mask, mask_is_f32, out, T, h, w, F, (hipStream_t)stream);
+}
+
 }  // extern "C"

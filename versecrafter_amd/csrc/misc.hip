@@ -170,6 +170,32 @@ inline int grid_for(int64_t n, int block) {
 }
 inline int ok() { return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP; }
 
+
+// geoada_context of one sample (pipeline_wan_versecrafter.py:440-488, ref_images = None):
+//   out[0:64]          = z                                   (VAE latents of the control videos)
+//   out[64 + dy*8+dx]  = mask[0][src(t)][8y+dy][8x+dx]       (8x8 pixel-unshuffle of mask channel 0, then
+//                                                             F.interpolate(mode="nearest-exact") over frames)
+// src(t) = min(floor((t + 0.5) * (F / T)), F - 1) evaluated in fp32 exactly as ATen's nearest-exact index.
+template <typename MaskT>
+__global__ __launch_bounds__(256) void geoada_context_kernel(const bf16_t* __restrict__ z, const MaskT* __restrict__ mask,
+                                                             bf16_t* __restrict__ out, int T, int h, int w, int F,
+                                                             float scale) {
+    const int64_t plane = (int64_t)h * w, vol = (int64_t)T * plane;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 128 * vol) return;
+    const int c = (int)(i / vol);
+    const int64_t rem = i - (int64_t)c * vol;
+    if (c < 64) { out[i] = z[i]; return; }
+    const int t = (int)(rem / plane);
+    const int yx = (int)(rem - (int64_t)t * plane);
+    const int y = yx / w, x = yx - y * w;
+    const int dy = (c - 64) >> 3, dx = (c - 64) & 7;
+    int src = (int)floorf(((float)t + 0.5f) * scale);
+    src = src < F - 1 ? src : F - 1;
+    const int64_t W = (int64_t)w * 8;
+    out[i] = (bf16_t)(float)mask[((int64_t)src * h * 8 + (y * 8 + dy)) * W + x * 8 + dx];
+}
+
 }  // namespace
 
 int vc_launch_patchify(const void* x, void* A, int B, int C, int T, int H, int W, int Lrows, int tok_offset,
@@ -253,5 +279,19 @@ int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hip
     if (!recv || !attn || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
     hipLaunchKernelGGL(sp_unpack_o_kernel, dim3(grid_for((int64_t)M * d / 8, 256)), dim3(256), 0, st,
                        (const bf16_t*)recv, (bf16_t*)attn, M, d / 8, d / P / 8);
+    return ok();
+}
+
+int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F,
+                             hipStream_t st) {
+    if (!z || !mask || !out || T <= 0 || h <= 0 || w <= 0 || F <= 0) return VC_E_INVALID;
+    const int64_t n = (int64_t)128 * T * h * w;
+    const float scale = (float)F / (float)T;
+    if (mask_is_f32)
+        hipLaunchKernelGGL(geoada_context_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)z,
+                           (const float*)mask, (bf16_t*)out, T, h, w, F, scale);
+    else
+        hipLaunchKernelGGL(geoada_context_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)z,
+                           (const bf16_t*)mask, (bf16_t*)out, T, h, w, F, scale);
     return ok();
 }

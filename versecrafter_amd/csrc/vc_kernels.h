@@ -88,6 +88,8 @@ int vc_launch_axpy(const void* a, const void* b, void* out, float s, int64_t n, 
 int vc_launch_sub(const void* a, const void* b, void* out, int64_t n, hipStream_t st);
 // zero-pad text rows: dst[b, i, :] = i < len[b] ? src_b[i, :] : 0      (VC.py:358-363)
 int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, hipStream_t st);
+int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F,
+                             hipStream_t st);
 // Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py):
 //   pack   qkv [M, 3d]       -> send [P_dst][3][M][d/P]
 //   unpack recv [P_src][M][d/P] -> attn [M, d]

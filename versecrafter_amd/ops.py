@@ -108,3 +108,27 @@ def rmsnorm_rope_(x, weight, eps=1e-6, table=None, grid=None, token_offset=0, ro
                                 _stream())
     _lib.check(rc)
     return x
+
+
+def geoada_context(z, mask):
+    """PIPE.py:440-488 for one sample: z [64,T,h,w] bf16 control latents, mask [C,F,H,W] (bf16 or fp32; channel 0 is
+    used, as in the reference) -> [128,T,h,w] bf16 = cat(z, nearest-exact frame resize of the 8x8 pixel-unshuffled mask)."""
+    lib = _lib.load()
+    _chk(z, "z")
+    if not mask.is_cuda:
+        raise RuntimeError("mask must be a CUDA (HIP) tensor: versecrafter_amd has no CPU path")
+    if mask.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"mask must be bfloat16 or float32, got {mask.dtype}")
+    if z.dim() != 4 or z.shape[0] != 64 or mask.dim() != 4:
+        raise ValueError(f"z must be [64,T,h,w] and mask [C,F,H,W]; got {tuple(z.shape)} and {tuple(mask.shape)}")
+    _, T, h, w = z.shape
+    _, F, H, W = mask.shape
+    z = z.contiguous()
+    m0 = mask[0].contiguous()
+    out = torch.empty(128, T, h, w, dtype=torch.bfloat16, device=z.device)
+    rc = lib.vc_op_geoada_context(_ptr(z), _ptr(m0), int(mask.dtype == torch.float32), _ptr(out), T, h, w, F, H, W,
+                                  _stream())
+    if rc != 0:
+        raise ValueError(f"geoada_context: mask {tuple(mask.shape)} does not map onto latents {tuple(z.shape)} "
+                         "(needs T = (F+3)//4, H = 8h, W = 8w, h and w even; PIPE.py:459-466)")
+    return out

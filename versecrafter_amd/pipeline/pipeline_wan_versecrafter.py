@@ -182,13 +182,19 @@ class WanVerseCrafterPipeline:
             vids = [(cv.to(torch.float32) * 2.0 - 1.0).to(dtype=weight_dtype, device=device) for cv in control_video]
             geoada_latents = self.geoada_encode_multi_frames(vids)
         geoada_latents = [z.to(device=device, dtype=weight_dtype) for z in geoada_latents]
-        if mask_latents is None:
-            if mask_video is None:
-                raise ValueError("mask_video (or mask_latents) is required")
-            mc = torch.tile(mask_video.to(torch.float32), [1, 3, 1, 1, 1]).to(dtype=weight_dtype, device=device)
-            mask_latents = geoada_encode_masks(mc)
-        mask_latents = [m.to(device=device, dtype=weight_dtype) for m in mask_latents]
-        geoada_context = geoada_latent(geoada_latents, mask_latents)                # [128, T, h, w] per sample
+        if mask_latents is None and mask_video is None:
+            raise ValueError("mask_video (or mask_latents) is required")
+        if mask_latents is None and device.type == "cuda" and weight_dtype == torch.bfloat16:
+            # PIPE.py:440-488 in one HIP kernel per sample (the reference tiles the mask to 3 channels and reads channel 0)
+            from .. import ops
+            mv = mask_video.to(device=device, dtype=torch.float32).to(weight_dtype)
+            geoada_context = [ops.geoada_context(z, m) for z, m in zip(geoada_latents, mv)]
+        else:
+            if mask_latents is None:
+                mc = torch.tile(mask_video.to(torch.float32), [1, 3, 1, 1, 1]).to(dtype=weight_dtype, device=device)
+                mask_latents = geoada_encode_masks(mc)
+            mask_latents = [m.to(device=device, dtype=weight_dtype) for m in mask_latents]
+            geoada_context = geoada_latent(geoada_latents, mask_latents)            # [128, T, h, w] per sample
 
         T, h, w = geoada_latents[0].shape[1:]
         latent_channels = getattr(getattr(self.vae, "config", None), "latent_channels", 16)
