@@ -258,21 +258,22 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 // Ping-pong kernel (production kernel for the engine's large GEMMs): 256x256x64 tile, 8 waves (2 x 4, 128x64 each),
 // 2 LDS stages of 64 KiB.  The two waves of a SIMD (wave w and w+4: groups G0 = rows 0-127, G1 = rows 128-255) run the
 // same program one barrier apart, so that at any time one of them is in a 16-MFMA section (one quadrant of its output
-// x K=64) and the other in a "load" section (4-12 ds_read_b128 fragment reads + the 2 LDS-DMA pieces that are its share
+// x K=64) and the other in a "load" section (4-8 ds_read_b128 fragment reads + the 2 LDS-DMA pieces that are its share
 // of one half-tile of a later K-tile).  Eight phases = two K-tiles per loop trip; per phase
-//     reads ; DMA ; [lgkmcnt] ; barrier ; MFMA x16 ; barrier
+//     reads ; DMA ; [vmcnt] ; barrier ; MFMA x16 ; barrier
 // K-tile image in LDS (per stage): [A half0 | A half1 | B half0 | B half1], 16 KiB each, where half h of A holds, for
 // both wave groups, the 64 rows each wave uses in its quadrants h (and likewise 32-row slices of B for the 4 wave
 // columns): a half is dead once the phase that reads it has passed, which is what lets its successor (K-tile + 2) be
 // staged while the K-tile is still being computed:
-//     phase 1: reads B0,A0 of E   stages Ah1 of O      phase 5: reads B0,A0 of O   stages Ah1 of E'
-//     phase 2: reads B1           stages Bh0 of E'     phase 6: reads B1           stages Bh0 of O'
-//     phase 3: reads A1           stages Ah0 of E'     phase 7: reads A1           stages Ah0 of O'
-//     phase 4: -                  stages Bh1 of E'     phase 8: -                  stages Bh1 of O'
-//              vmcnt(6): O landed                               vmcnt(6): E' landed
-// (E/O = K-tile in the even/odd stage, ' = two K-tiles later).  WAR: a half is restaged two phases after its last
-// read, except Bh0 (one phase; its 4 reads are issued first in phases 1/5 and retired by lgkmcnt(8) before the
-// barrier).  RAW: the counted vmcnt sits before a barrier that every reader passes before its first read.
+//     phase 1: reads A0 of E      stages Ah1 of O      phase 5: reads A0 of O      stages Ah1 of E'
+//     phase 2: reads B1 of E      stages Bh0 of E'     phase 6: reads B1 of O      stages Bh0 of O'
+//     phase 3: reads A1 of E      stages Ah0 of E'     phase 7: reads A1 of O      stages Ah0 of O'
+//              vmcnt(4): O landed                               vmcnt(4): E' landed
+//     phase 4: reads B0 of O      stages Bh1 of E'     phase 8: reads B0 of E'     stages Bh1 of O'
+// (E/O = K-tile in the even/odd stage, ' = two K-tiles later).  The B0 fragments of a K-tile are read during the last
+// phase of the previous one, into the register set that held its B1 (dead after phase 3): 8/4/8/4 reads per phase.
+// WAR: a half is restaged two phases after its last read.  RAW: the counted vmcnt (all but the two youngest half-tiles)
+// sits before a barrier that every reader passes before its first read of that K-tile, one phase later.
 // Rows past M are read (never stored): the caller guarantees they are readable (a_rows_padded / M % 256 == 0).
 // Past the last K-tile the staging re-reads the last K-tile into a dead stage (keeps vmcnt counts uniform).
 // =====================================================================================================
@@ -356,14 +357,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             af[i][1] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc1);
         }
     };
+    // B fragments of half hh of the K-tile in `stage` live in register set hh ^ stage: the set that held B1 of one K-tile
+    // is dead after that K-tile's third phase and receives B0 of the NEXT K-tile during its fourth (see the loop)
     auto read_b = [&](int stage, int hh) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bf[hh][j][0] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
-            bf[hh][j][1] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
+            bf[hh ^ stage][j][0] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
+            bf[hh ^ stage][j][1] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
         }
     };
-    auto mma = [&](int ah, int bh) {   // quadrant (A half ah, B half bh) x K=64: 16 MFMA
+    auto mma = [&](int ah, int bh, int stage) {   // quadrant (A half ah, B half bh) x K=64: 16 MFMA
+        const int bs = bh ^ stage;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[ah * 4 + i][bh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[bh][j][ks], af[i][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[bs][j][ks], af[i][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 #define VC_PP_BARRIER()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -384,39 +388,41 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     VC_PP_WAIT("s_waitcnt vmcnt(6)");
     VC_PP_BARRIER();
     if (wr == 1) VC_PP_BARRIER();          // group 1 runs one barrier behind group 0
+    read_b(0, 0);                          // B0 of K-tile 0 (later ones are read during the previous K-tile's 4th phase)
+    __builtin_amdgcn_sched_barrier(0);
 
     for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {     // st = 0: K-tile kt (even stage), st = 1: K-tile kt+1 (odd stage)
-            // phase 1 / 5
-            read_b(st, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            // phase 1 / 5: reads A0
             read_a(st, 0);
             __builtin_amdgcn_sched_barrier(0);
             stage_half(st ^ 1, 1, kt + 1 + st);                 // Ah1 of the other stage's next K-tile
-            VC_PP_WAIT("s_waitcnt lgkmcnt(8)");                  // the 4 B reads are done: Bh0 may be restaged next phase
             VC_PP_BARRIER();
-            mma(0, 0);
+            mma(0, 0, st);
             VC_PP_BARRIER();
-            // phase 2 / 6
+            // phase 2 / 6: reads B1
             read_b(st, 1);
             __builtin_amdgcn_sched_barrier(0);
             stage_half(st, 2, kt + 2 + st);                      // Bh0 of this stage's next K-tile
             VC_PP_BARRIER();
-            mma(0, 1);
+            mma(0, 1, st);
             VC_PP_BARRIER();
-            // phase 3 / 7
+            // phase 3 / 7: reads A1; the other stage's K-tile has landed (this wave's pieces) once all but the two
+            // youngest half-tiles are retired
             read_a(st, 1);
             __builtin_amdgcn_sched_barrier(0);
             stage_half(st, 0, kt + 2 + st);                      // Ah0
+            VC_PP_WAIT("s_waitcnt vmcnt(4)");
             VC_PP_BARRIER();
-            mma(1, 1);
+            mma(1, 1, st);
             VC_PP_BARRIER();
-            // phase 4 / 8
+            // phase 4 / 8: reads B0 of the NEXT K-tile (other stage; its set of registers held this K-tile's B1)
+            read_b(st ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
             stage_half(st, 3, kt + 2 + st);                      // Bh1
-            VC_PP_WAIT("s_waitcnt vmcnt(6)");                    // the other stage's K-tile has landed (this wave's pieces)
             VC_PP_BARRIER();
-            mma(1, 0);
+            mma(1, 0, st);
             VC_PP_BARRIER();
         }
     }
