@@ -135,6 +135,31 @@ int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, fl
 int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F, int H,
                          int W, void* stream);
 
+/* ---- umT5 text encoder --------------------------------------------------------------------------
+ * Replaces WanT5EncoderModel (videox_fun, un-vendored; origin Wan2.1 wan/modules/t5.py) as the reference's pipeline
+ * uses it: `self.text_encoder(ids, attention_mask=mask)[0]` (pipeline_wan_versecrafter.py:273), constructed at
+ * inference/versecrafter_inference.py:243-249 with config/wan2.1/wan_civitai.yaml:14-26.
+ * Weights are borrowed device pointers (bf16) addressed by the upstream state-dict keys:
+ *   token_embedding.weight [vocab,dim], norm.weight [dim], and per layer i = blocks.i.:
+ *   norm1.weight, attn.{q,k,v}.weight [dim_attn,dim], attn.o.weight [dim,dim_attn], norm2.weight,
+ *   ffn.gate.0.weight, ffn.fc1.weight [dim_ffn,dim], ffn.fc2.weight [dim,dim_ffn],
+ *   pos_embedding.embedding.weight [num_buckets,num_heads]. */
+typedef struct vc_t5_config {
+    int32_t vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets, max_distance;
+    float eps;
+} vc_t5_config;
+typedef struct vc_t5 vc_t5;
+int vc_t5_create(const vc_t5_config* cfg, vc_t5** out);
+int vc_t5_load_weight(vc_t5* h, const char* key, const void* dev_ptr, int ndim, const int64_t* shape);
+/* ids, mask: DEVICE int32 [B, L] (mask 1 = token, 0 = padding; NULL = no padding); out: DEVICE bf16 [B, L, dim].
+ * L must be a multiple of 64 (the reference pads every prompt to text_length = 512). */
+int vc_t5_encode(vc_t5* h, const int32_t* ids, const int32_t* mask, void* out, int B, int L, void* stream);
+/* host-only: bidirectional T5 bucket of rel = key - query (what the encoder's table holds); -1 on bad arguments */
+int vc_t5_relative_bucket(int rel, int num_buckets, int max_distance);
+const char* vc_t5_last_error(const vc_t5* h);
+int64_t vc_t5_workspace_bytes(const vc_t5* h);
+void vc_t5_destroy(vc_t5* h);
+
 #ifdef __cplusplus
 }
 #endif

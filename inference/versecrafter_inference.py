@@ -66,6 +66,13 @@ def parse_args(argv=None):
                    help="random control latents / prompt embeddings instead of VAE + T5 + mp4 decoding")
     p.add_argument("--synthetic_model", type=str, default=None, choices=[None, "14b", "1.3b", "tiny"],
                    help="random weights of the named architecture instead of --transformer_path")
+    p.add_argument("--text_encoder_path", type=str, default=None,
+                   help="umT5 checkpoint (models_t5_umt5-xxl-enc-bf16.pth or .safetensors): encode --prompt and the fixed negative prompt "
+                        "with the HIP text encoder instead of random embeddings (needs --tokenizer_path)")
+    p.add_argument("--tokenizer_path", type=str, default=None, help="local directory of the google/umt5-xxl tokenizer files")
+    p.add_argument("--control_latents_path", type=str, default=None,
+                   help=".safetensors with 'geoada_latents' [64,T,h,w] (VAE latents of the 4 control videos) and "
+                        "'mask_video' [1,F,H,W] (merged mask) -- stands in for the out-of-scope Wan VAE encode")
     return p.parse_args(argv)
 
 
@@ -93,14 +100,20 @@ def main(argv=None):
             low_cpu_mem_usage=True, torch_dtype=weight_dtype).to(device)
 
     vae = text_encoder = tokenizer = None
-    if not args.synthetic_inputs:
-        try:
-            from videox_fun.models import AutoencoderKLWan, AutoTokenizer, WanT5EncoderModel   # noqa: F401
-            from videox_fun.utils.utils import get_image_latent, get_video_to_video_latent, save_videos_grid  # noqa
-        except ImportError as e:
-            raise SystemExit(f"{e}: the Wan VAE / umT5 / video IO come from the third-party VideoX-Fun package, which is "
-                             "not part of this build; use --synthetic_inputs or install it next to this repo") from e
-        raise SystemExit("VideoX-Fun found: wire its VAE/T5 loaders here exactly as CLI.py:220-249, 351-417 do")
+    if args.text_encoder_path:                                                      # CLI.py:238-249
+        if not args.tokenizer_path:
+            raise SystemExit("--text_encoder_path needs --tokenizer_path (local google/umt5-xxl tokenizer files)")
+        from transformers import AutoTokenizer
+        from versecrafter_amd.models import WanT5EncoderModel
+        tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_path)
+        text_encoder = WanT5EncoderModel.from_pretrained(
+            args.text_encoder_path, additional_kwargs=dict(vocab=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64,
+                                                           num_layers=24, num_buckets=32, shared_pos=False, dropout=0.0),
+            low_cpu_mem_usage=True, torch_dtype=weight_dtype).eval()
+    if not args.synthetic_inputs and not (args.text_encoder_path and args.control_latents_path):
+        raise SystemExit("a real run needs --text_encoder_path/--tokenizer_path and --control_latents_path (the Wan VAE and "
+                         "mp4 decoding belong to the third-party VideoX-Fun package and are not part of this build); "
+                         "otherwise pass --synthetic_inputs")
 
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)  # CLI.py:252-261
     pipeline = WanVerseCrafterPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae,
@@ -119,16 +132,25 @@ def main(argv=None):
     generator = torch.Generator(device=device).manual_seed(args.seed)               # CLI.py:319
     T, h, w = (args.video_length - 1) // 4 + 1, height // 8, width // 8
     g = torch.Generator().manual_seed(args.seed)
-    ctrl = torch.randn(64, T, h, w, generator=g)
-    mask = (torch.rand(64, T, h, w, generator=g) < 0.5).float()
-    mask[:, 0] = 0                                                                  # CLI.py:395
-    embeds = dict(prompt_embeds=[torch.randn(77, transformer.text_dim, generator=g)],
-                  negative_prompt_embeds=[torch.randn(60, transformer.text_dim, generator=g)])
+    if args.control_latents_path:
+        from safetensors.torch import load_file
+        cl = load_file(args.control_latents_path)
+        control = dict(geoada_latents=[cl["geoada_latents"]], mask_video=cl["mask_video"][None].float())
+    else:
+        ctrl = torch.randn(64, T, h, w, generator=g)
+        mask = (torch.rand(64, T, h, w, generator=g) < 0.5).float()
+        mask[:, 0] = 0                                                              # CLI.py:395
+        control = dict(geoada_latents=[ctrl], mask_latents=[mask])
+    if text_encoder is not None:
+        embeds = dict(prompt=args.prompt, negative_prompt=NEGATIVE_PROMPT)                     # CLI.py:421-423
+    else:
+        embeds = dict(prompt_embeds=[torch.randn(77, transformer.text_dim, generator=g)],
+                      negative_prompt_embeds=[torch.randn(60, transformer.text_dim, generator=g)])
     t0 = time.time()
     sample = pipeline(height=height, width=width, num_frames=args.video_length, generator=generator,
                       guidance_scale=args.guidance_scale, num_inference_steps=args.num_inference_steps,
-                      geoada_latents=[ctrl], mask_latents=[mask], shift=args.shift,
-                      geoada_context_scale=args.geoada_context_scale, output_type="latent", **embeds).videos
+                      shift=args.shift, geoada_context_scale=args.geoada_context_scale, output_type="latent",
+                      **control, **embeds).videos
     torch.cuda.synchronize()
     dt = time.time() - t0
     rank = int(os.environ.get("RANK", 0))

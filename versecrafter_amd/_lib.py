@@ -25,6 +25,12 @@ class vc_config(C.Structure):
                 ("geoada_layers", C.c_int32 * VC_MAX_GEOADA_LAYERS)]
 
 
+class vc_t5_config(C.Structure):
+    _fields_ = [("vocab", C.c_int32), ("dim", C.c_int32), ("dim_attn", C.c_int32), ("dim_ffn", C.c_int32),
+                ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("num_buckets", C.c_int32),
+                ("max_distance", C.c_int32), ("eps", C.c_float)]
+
+
 ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -52,6 +58,13 @@ SYMBOLS = {
     "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
     "vc_op_geoada_context": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vc_t5_create": (_I, [C.POINTER(vc_t5_config), C.POINTER(_P)]),
+    "vc_t5_load_weight": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L)]),
+    "vc_t5_encode": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "vc_t5_relative_bucket": (_I, [_I, _I, _I]),
+    "vc_t5_last_error": (C.c_char_p, [_P]),
+    "vc_t5_workspace_bytes": (_L, [_P]),
+    "vc_t5_destroy": (None, [_P]),
 }
 
 _lib = None

@@ -235,6 +235,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+            } else if (p.epilogue == VC_EPI_GELU_MUL) {
+                float r[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
             } else if (p.epilogue == VC_EPI_BIAS_GATE_RESID) {
                 float r[4], g[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
@@ -462,6 +467,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+            } else if (p.epilogue == VC_EPI_GELU_MUL) {
+                float r[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
             } else if (p.epilogue == VC_EPI_BIAS_GATE_RESID) {
                 float r[4], gg[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
@@ -523,7 +533,7 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
     if (p.K % 64 != 0 || p.N % 4 != 0) return VC_E_UNSUPPORTED;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 4)) return VC_E_UNSUPPORTED;
-    if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID) && (!p.resid || p.ldr % 4))
+    if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID || p.epilogue == VC_EPI_GELU_MUL) && (!p.resid || p.ldr % 4))
         return VC_E_INVALID;
     if (p.epilogue == VC_EPI_BIAS_GATE_RESID && !p.gate) return VC_E_INVALID;
     if (p.ngroups < 0 || p.ngroups > 3) return VC_E_INVALID;

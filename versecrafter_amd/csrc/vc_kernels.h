@@ -18,6 +18,7 @@ enum VcEpilogue {
     VC_EPI_BIAS_GELU = 1,   // C = gelu_tanh(acc + bias)
     VC_EPI_BIAS_RESID = 2,  // C = resid + (acc + bias)
     VC_EPI_BIAS_GATE_RESID = 3,  // C = resid + (acc + bias) * gate[b, n]  (+ hint * hint_scale)
+    VC_EPI_GELU_MUL = 4,    // C = gelu_tanh(acc + bias) * resid      (T5 gated-GELU feed-forward: gate(x) * fc1(x))
 };
 
 struct VcGemmParams {
