@@ -120,6 +120,12 @@ int vc_op_attention(const void* q, const void* k, const void* v, void* out, int 
                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                     const int64_t* o_strides, int k_len, float scale, void* stream);
 
+/* The same attention on the Ulysses receive layout (token axis in segments of seg_len tokens, one per source rank):
+ * strides are {batch, token within a segment, head, segment}; token t = (t / seg_len, t % seg_len).  Lq = Lk = L. */
+int vc_op_attention_segmented(const void* q, const void* k, const void* v, void* out, int B, int H, int L,
+                              const int64_t* q_strides4, const int64_t* k_strides4, const int64_t* v_strides4,
+                              const int64_t* o_strides4, int seg_len, int k_len, float scale, void* stream);
+
 /* WanLayerNorm + modulate (mode 0: y = LN(x)*(1+p0[b])+p1[b]) or affine (mode 1: y = LN(x)*p0+p1). */
 int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
                     const void* p0, const void* p1, int64_t p_bstride, void* stream);

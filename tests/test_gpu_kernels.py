@@ -209,6 +209,24 @@ def test_attention_packed_qkv_layout(ops):
     assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="packed")
 
 
+@pytest.mark.parametrize("S,Ls,k_len", [(2, 333, 0), (4, 100, 390), (8, 67, 0), (3, 64, 0), (2, 1000, 1999), (5, 40, 0),
+                                        (8, 4095, 0), (2, 16380, 0)])      # cfg-3 at P = 8 and P = 2
+def test_attention_segmented_layout_equals_contiguous_bitwise(ops, S, Ls, k_len):
+    """The Ulysses receive layout [segment][batch][token][head]: segment lengths that are not multiples of the 4-row staging
+    pieces or of the 64-key tile (pieces straddling a boundary take the per-row path, pieces past it the next segment's
+    base), below one tile (generic path), with and without a masked tail.  Same arithmetic => bit-identical."""
+    rs = np.random.RandomState(S * 1000 + Ls)
+    B, H = 2, 3
+    L = S * Ls
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for _ in range(3))
+    want = ops.attention(dev(q), dev(k), dev(v), k_len=k_len)
+    seg = lambda t: dev(t).view(B, S, Ls, H, 128).permute(1, 0, 2, 3, 4).contiguous()
+    got = ops.attention_segmented(seg(q), seg(k), seg(v), k_len=k_len)
+    got = got.permute(1, 0, 2, 3, 4).reshape(B, L, H, 128)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all() and torch.equal(got, want)
+
+
 def test_attention_large_logits_rescale(ops):
     """Force the online-softmax rescale: one key row far larger than the running max, late in the sequence."""
     rs = np.random.RandomState(4)

@@ -823,6 +823,21 @@ int vc_op_attention(const void* q, const void* k, const void* v, void* out, int 
     return vc_launch_attention(a, (hipStream_t)stream);
 }
 
+int vc_op_attention_segmented(const void* q, const void* k, const void* v, void* out, int B, int H, int L,
+                              const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, int seg_len,
+                              int k_len, float scale, void* stream) {
+    // strides: {batch, token-within-segment, head, segment}; token t lives at (t / seg_len) * ss + (t % seg_len) * ts
+    if (!qs || !ks || !vs || !os || seg_len <= 0) return VC_E_INVALID;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2]; a.q_ss = qs[3];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2]; a.k_ss = ks[3];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2]; a.v_ss = vs[3];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2]; a.o_ss = os[3];
+    a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.k_len = k_len; a.scale = scale; a.seg_len = seg_len;
+    return vc_launch_attention(a, (hipStream_t)stream);
+}
+
 int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode, const void* p0,
                     const void* p1, int64_t p_bstride, void* stream) {
     return vc_launch_layernorm(x, y, rows, dim, rows_per_batch, eps, mode, p0, p1, p_bstride, (hipStream_t)stream);

@@ -65,6 +65,24 @@ def attention(q, k, v, k_len=0, scale=None, out=None):
     return out
 
 
+def attention_segmented(q, k, v, k_len=0, scale=None):
+    """Attention on the Ulysses receive layout: q, k, v [S, B, Lseg, H, 128] (segment s holds tokens s*Lseg .. of the
+    sequence) -> out in the same layout.  Equivalent to attention() on the [B, S*Lseg, H, 128] concatenation."""
+    lib = _lib.load()
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    S, B, Ls, H, D = q.shape
+    assert D == 128 and k.shape == q.shape and v.shape == q.shape
+    assert q.stride(4) == 1 and k.stride(4) == 1 and v.stride(4) == 1
+    out = torch.empty(S, B, Ls, H, D, dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    st = lambda t: (C.c_int64 * 4)(t.stride(1), t.stride(2), t.stride(3), t.stride(0))
+    rc = lib.vc_op_attention_segmented(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, S * Ls, st(q), st(k), st(v), st(out),
+                                       Ls, int(k_len), float(scale), _stream())
+    _lib.check(rc)
+    return out
+
+
 def layernorm_modulate(x, scale, shift, rows_per_batch, eps=1e-6):
     """y = LN(x) * (1 + scale[b]) + shift[b];  x [rows, dim], scale/shift [B, dim] (same row stride)."""
     lib = _lib.load()
