@@ -66,10 +66,12 @@ VC_DEVICE float wave_max(float v) {
 VC_DEVICE float gelu_tanh_f(float x) {
     // nn.GELU(approximate='tanh'): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1); exp overflow -> inf -> tanh = 1, underflow -> -1
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
+    const float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1) on the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 by every caller):
+    // exp overflow -> inf -> rcp 0 -> tanh = 1, underflow -> 0 -> tanh = -1.  An IEEE division here costs ~10 instructions
+    // per element of every FFN-1 output tile.
+    const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
     return 0.5f * x * (1.0f + t);
 }
 VC_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
