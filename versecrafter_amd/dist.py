@@ -58,13 +58,31 @@ def get_sequence_parallel_rank():
 
 
 # ---- byte-level collectives (device-agnostic torch plumbing) --------------------------------------
+def _host_bounce(t: torch.Tensor, group) -> bool:
+    """gloo has no device all-to-all / all-gather: device buffers are staged through host memory.  This is the functional
+    transport of the multi-process tests on one GPU; the product transport is RCCL ("nccl"), which never takes it."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_to_all_bytes(send: torch.Tensor, recv: torch.Tensor, group=None):
     """send / recv: flat uint8 tensors of P equal slices; slice r of `send` goes to rank r."""
+    if _host_bounce(send, group):
+        h_send = send.cpu()                      # waits for the producer kernels on the current stream
+        h_recv = torch.empty_like(h_send)
+        dist.all_to_all_single(h_recv, h_send, group=group)
+        recv.copy_(h_recv)
+        return
     dist.all_to_all_single(recv, send, group=group)
 
 
 def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None):
     """recv (P * len(send)) = concatenation over ranks of `send`."""
+    if _host_bounce(send, group):
+        h_send = send.cpu()
+        h_recv = torch.empty(recv.numel(), dtype=recv.dtype)
+        dist.all_gather_into_tensor(h_recv, h_send, group=group)
+        recv.copy_(h_recv)
+        return
     dist.all_gather_into_tensor(recv, send, group=group)
 
 
