@@ -97,6 +97,12 @@ def main():
                          "and report them as a separate 'teacache_on' object; 0 = off (the headline metric is TeaCache-off)")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner on stdout when the first communicator is
+    # created, other libraries may chatter too.  Route fd 1 to stderr for the whole run and keep the real stdout aside.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,7 +244,8 @@ def main():
             out["teacache_on"] = tea
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mk, f_step)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
