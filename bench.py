@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (model kwargs, frames, height, width)
     "wan14b-81f-480x832": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 81, 480, 832),
     "wan14b-49f-480x832": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 49, 480, 832),
+    "wan14b-81f-720x1280": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 81, 720, 1280),   # BASELINE config 4
     "wan1.3b-9f-320x512": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), 9, 320, 512),
     "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=4, text_dim=64, text_len=48), 9, 64, 96),
 }
