@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
         }
     }
     const float mean = wave_sum(s) / (float)dim;
+    // keep the ROW (packed bf16, MAXC x 4 registers) live across the passes, not its fp32 expansion (x 2 the registers):
+    // the opaque asm stops the compiler from reusing the unpacked values, which would cost 3 of 8 waves per SIMD
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) asm volatile("" : "+v"(raw[c].x), "+v"(raw[c].y), "+v"(raw[c].z), "+v"(raw[c].w));
     float v = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -51,6 +55,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
         }
     }
     const float rstd = rsqrtf(wave_sum(v) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) asm volatile("" : "+v"(raw[c].x), "+v"(raw[c].y), "+v"(raw[c].z), "+v"(raw[c].w));
     const int b = rows_per_batch > 0 ? row / rows_per_batch : 0;
     const bf16_t* q0 = mode == 0 ? p0 + (int64_t)b * p_bstride : p0;   // scale (mode 0) | weight (mode 1)
     const bf16_t* q1 = mode == 0 ? p1 + (int64_t)b * p_bstride : p1;   // shift (mode 0) | bias   (mode 1)
@@ -99,6 +105,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
         }
     }
     const float inv = round_bf16(rsqrtf(wave_sum(ss) / (float)dim + eps));   // rsqrt(...).to(bf16), WT.py:323
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) asm volatile("" : "+v"(raw[c].x), "+v"(raw[c].y), "+v"(raw[c].z), "+v"(raw[c].w));   // as in layernorm_kernel
 
     // RoPE multipliers: this lane's 4 pairs have the same in-head pair index j0..j0+3 in every chunk
     float cs[4], sn[4];
