@@ -17,7 +17,7 @@ def find(d, suffix):
 
 
 def short(name):
-    for k in ("attn_fwd_pipe_kernel", "attn_fwd_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
+    for k in ("attn_fwd_pipe_kernel", "attn_fwd_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "t5_attention_kernel", "geoada_context_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
               "unpatchify_kernel", "small_linear_kernel", "modulation_kernel", "axpy_kernel", "copy_strided_kernel"):
         if k in name:
             if k == "gemm_bf16_kernel":
