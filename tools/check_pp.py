@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from versecrafter_amd import ops
+TILE = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 g = torch.Generator(device="cuda").manual_seed(0)
 for (M, N, K) in ((1024, 256, 128), (1024, 256, 256), (1100, 512, 1024), (2048, 768, 384), (65520, 5120, 5120), (65520, 5120, 13824)):
     MP = (M + 255) // 256 * 256
@@ -13,8 +14,8 @@ for (M, N, K) in ((1024, 256, 128), (1024, 256, 256), (1100, 512, 1024), (2048, 
     w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
     bias = torch.zeros(N, device="cuda").bfloat16()
     o2 = ops.gemm(a, w, bias, tile=2)
-    o4 = ops.gemm(a, w, bias, tile=4)
-    o4b = ops.gemm(a, w, bias, tile=4)
+    o4 = ops.gemm(a, w, bias, tile=TILE)
+    o4b = ops.gemm(a, w, bias, tile=TILE)
     torch.cuda.synchronize()
     ne = (o2 != o4)
     print(f"M={M} N={N} K={K}: mismatches {int(ne.sum())} / {ne.numel()}  rerun-identical {torch.equal(o4, o4b)} "
