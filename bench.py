@@ -240,6 +240,10 @@ def main():
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
+            if world > 1:
+                out["roofline"]["note"] = ("sequence-parallel run: the GeoAdapter chain runs on its own stream, so launches of the "
+                                           "two chains overlap and the per-launch durations (hence 'achieved') are lower bounds; "
+                                           "the N=1 line carries the kernel roofline")
             out["breakdown"] = bd
         if tea is not None:
             out["teacache_on"] = tea
