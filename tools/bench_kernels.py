@@ -63,6 +63,18 @@ def bench_attn():
     print(f"attn cross Lk=512: median {med:.3f} ms ({fl / med / 1e9:.0f} TF)", flush=True)
 
 
+def bench_attn_seg():
+    """Self-attention of one rank of a P = 8 / P = 2 sequence-parallel run (Ulysses receive layout, heads / P)."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for S, Ls, H in ((8, 4095, 5), (2, 16380, 20)):
+        B = 2
+        q, k, v = (torch.randn(S, B, Ls, H, 128, device="cuda", generator=g).bfloat16() for _ in range(3))
+        med, mn = timeit(lambda: ops.attention_segmented(q, k, v), rounds=4, inner=2)
+        fl = 4.0 * B * H * (S * Ls) ** 2 * 128
+        print(f"attn segmented S={S} Ls={Ls} H={H}: median {med:.3f} ms ({fl / med / 1e9:.0f} TF) min {mn:.3f} ms "
+              f"({fl / mn / 1e9:.0f} TF)", flush=True)
+
+
 def bench_row():
     g = torch.Generator(device="cuda").manual_seed(0)
     M, d = 65520, 5120
@@ -78,5 +90,7 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+    if "attnseg" in what:
+        bench_attn_seg()
     if "row" in what:
         bench_row()
