@@ -89,6 +89,61 @@ def test_teacache_residual_path(model, fwd):
         model.disable_teacache()
 
 
+def test_enable_riflex_reaches_the_engine_and_is_reversible(fwd):
+    """enable_riflex (WT.py:873-888, CLI.py:315-317) replaces one temporal frequency of the RoPE table (checked against the
+    reference's table in test_oracle_golden.py).  On a 3-frame clip its effect on the output (2e-3 relative) is below the
+    bf16 noise of a forward, so the engine check is structural: the table reaches the kernels (output changes, equals a
+    model that had RIFLEx enabled from the start bit for bit, stays within the oracle bound) and disable_riflex restores it."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    cfg = O.Config(**TINY)
+    W = O.random_weights(cfg, 7)
+
+    def make():
+        m = VerseCrafterWanTransformer3DModel(**TINY)
+        m.load_state_dict(W)
+        return m.to(torch.bfloat16).to("cuda")
+
+    m = make()
+    seq_len = int(fwd["A.seq_len"])
+    base = run(m, fwd, seq_len)
+    m.enable_riflex(k=1, L_test=3)
+    got = run(m, fwd, seq_len)
+    assert not torch.equal(got, base)
+    fresh = make()
+    fresh.enable_riflex(k=1, L_test=3)
+    assert torch.equal(run(fresh, fwd, seq_len), got)
+    Wb = {k: v.bfloat16().float() for k, v in W.items()}
+    x, g = fwd["A.x"].bfloat16().float(), fwd["A.geoada"].bfloat16().float()
+    ctx = [fwd["A.ctx0"].bfloat16().float(), fwd["A.ctx1"].bfloat16().float()]
+    want = O.forward(Wb, cfg, x, fwd["A.t"], g, ctx, seq_len,
+                     freqs=O.rope_table_riflex(TINY["dim"] // TINY["num_heads"], 1, 3, 4.886))
+    assert rel(got, want) < 3e-2
+    m.disable_riflex()
+    assert torch.equal(run(m, fwd, seq_len), base)
+
+
+def test_cfg_skip_runs_conditional_half_only(model, fwd):
+    """cfg_skip (third-party decorator bound at WT.py:850-871; CLI.py:313): for the last `ratio` of the steps only the
+    conditional half is computed and returned twice."""
+    seq_len = int(fwd["A.seq_len"])
+    full = run(model, fwd, seq_len)
+    model.enable_cfg_skip(0.5, 4)
+    try:
+        model.current_steps = 0
+        assert torch.equal(run(model, fwd, seq_len), full)            # early step: both halves
+        model.current_steps = 3
+        late = run(model, fwd, seq_len)                               # late step: conditional half, duplicated
+        assert late.shape == full.shape and torch.equal(late[0], late[1])
+        x1 = fwd["A.x"][1:].bfloat16().cuda()
+        ctx1 = [fwd["A.ctx1"].bfloat16().cuda()]
+        model.disable_cfg_skip()
+        single = model(x1, fwd["A.t"][1:].cuda(), fwd["A.geoada"][1:].bfloat16().cuda(), ctx1, seq_len)
+        assert torch.equal(late[1:], single)
+    finally:
+        model.disable_cfg_skip()
+    assert torch.equal(run(model, fwd, seq_len), full)
+
+
 def test_errors_mirror_reference(model, fwd):
     ctx = [fwd["A.ctx0"].bfloat16().cuda(), fwd["A.ctx1"].bfloat16().cuda()]
     x, g, t = fwd["A.x"].bfloat16().cuda(), fwd["A.geoada"].bfloat16().cuda(), fwd["A.t"].cuda()
