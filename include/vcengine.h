@@ -141,6 +141,16 @@ int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, fl
 int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F, int H,
                          int W, void* stream);
 
+/* One sampler update on the latent (PIPE.py:903-909; third-party FlowUniPCMultistepScheduler.step, restated in
+ * versecrafter_amd/utils/fm_solvers_unipc.py) fused into one pass over n bf16 elements:
+ *   noise = u + g (c - u)  [flags&1]; x0 = sample - sigma_t noise; corrected sample [flags&2, order 2: flags&4];
+ *   next sample = UniPC predictor [order 2: flags&8].  Each op rounds to bf16 exactly as the torch formulation does.
+ * scalars13 (HOST): {guidance, sigma_t, ca, cb, cBh, rk_c, rho0_c, rho1_c, pa, pb, pBh, rk_p, rho_p}.
+ * m0 / m1: the previous two x0 predictions; last: the previous (corrected) sample; samp_out may be NULL. */
+int vc_op_unipc_update(const void* noise_uncond, const void* noise_cond, const void* sample, const void* last,
+                       const void* m0, const void* m1, void* x0_out, void* samp_out, void* next_out, int64_t n,
+                       const float* scalars13, int flags, void* stream);
+
 /* ---- umT5 text encoder --------------------------------------------------------------------------
  * Replaces WanT5EncoderModel (videox_fun, un-vendored; origin Wan2.1 wan/modules/t5.py) as the reference's pipeline
  * uses it: `self.text_encoder(ids, attention_mask=mask)[0]` (pipeline_wan_versecrafter.py:273), constructed at

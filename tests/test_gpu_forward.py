@@ -308,3 +308,33 @@ def test_cfg3_full_model_properties():
     assert torch.equal(c, a.flip(0))
     del m
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n_steps,shift,do_cfg", [(8, 16.0, True), (5, 5.0, True), (6, 16.0, False), (2, 16.0, True)])
+def test_fused_sampler_update_equals_torch_formulation_bitwise(n_steps, shift, do_cfg):
+    """PIPE.py:903-909 -- CFG combine + scheduler.step -- as one HIP kernel (FlowUniPCMultistepScheduler.step_cfg ->
+    vc_op_unipc_update) against the op-by-op torch formulation on the same device tensors: every step of a run must agree
+    bit for bit (first step without corrector, order-1 and order-2 corrector / predictor, lower-order final step)."""
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    g = torch.Generator().manual_seed(n_steps * 100 + int(shift))
+    shape = (1, 16, 3, 8, 12)
+    x = torch.randn(shape, generator=g).bfloat16().cuda()
+    a = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    b = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    a.set_timesteps(n_steps, device="cuda", shift=shift)
+    b.set_timesteps(n_steps, device="cuda", shift=shift)
+    xa, xb = x.clone(), x.clone()
+    guidance = 5.0
+    for i, t in enumerate(a.timesteps):
+        npred = torch.randn((2 if do_cfg else 1,) + shape[1:], generator=g).bfloat16().cuda()
+        if do_cfg:
+            u, c = npred.chunk(2)
+            noise = u + guidance * (c - u)
+        else:
+            noise = npred
+        xa = a.step(noise, t, xa, return_dict=False)[0]
+        xb = b.step_cfg(npred, t, xb, guidance if do_cfg else None)
+        torch.cuda.synchronize()
+        assert xb.dtype == torch.bfloat16 and torch.equal(xa, xb), f"step {i}: max diff {(xa.float() - xb.float()).abs().max()}"
+        assert torch.equal(a.model_outputs[-1], b.model_outputs[-1]) and torch.equal(a.last_sample, b.last_sample)
+    assert torch.isfinite(xb.float()).all()

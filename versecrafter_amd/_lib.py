@@ -60,6 +60,7 @@ SYMBOLS = {
     "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
     "vc_op_geoada_context": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vc_op_unipc_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, C.POINTER(_F), _I, _P]),
     "vc_t5_create": (_I, [C.POINTER(vc_t5_config), C.POINTER(_P)]),
     "vc_t5_load_weight": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L)]),
     "vc_t5_encode": (_I, [_P, _P, _P, _P, _I, _I, _P]),

@@ -862,4 +862,11 @@ int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void*
     return vc_launch_geoada_context(z, mask, mask_is_f32, out, T, h, w, F, (hipStream_t)stream);
 }
 
+int vc_op_unipc_update(const void* noise_uncond, const void* noise_cond, const void* sample, const void* last,
+                       const void* m0, const void* m1, void* x0_out, void* samp_out, void* next_out, int64_t n,
+                       const float* scalars13, int flags, void* stream) {
+    return vc_launch_unipc_update(noise_uncond, noise_cond, sample, last, m0, m1, x0_out, samp_out, next_out, n, scalars13,
+                                  flags, (hipStream_t)stream);
+}
+
 }  // extern "C"

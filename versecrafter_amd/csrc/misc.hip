@@ -196,6 +196,53 @@ __global__ __launch_bounds__(256) void geoada_context_kernel(const bf16_t* __res
     out[i] = (bf16_t)(float)mask[((int64_t)src * h * 8 + (y * 8 + dy)) * W + x * 8 + dx];
 }
 
+
+// One sampler update on the latent (pipeline_wan_versecrafter.py:903-909): classifier-free-guidance combine, flow
+// prediction -> x0, UniPC corrector (uses the previous sample and x0 history) and UniPC predictor, in ONE pass.
+// Every elementwise op of the torch formulation (utils/fm_solvers_unipc.py, restating the third-party
+// FlowUniPCMultistepScheduler) rounds its result to bf16; the kernel reproduces those roundings op for op, so the result is
+// bit-identical to the unfused path.  Scalars (sc[]) are computed on the host exactly as the scheduler computes them.
+struct VcUnipcScalars {
+    float guidance, sigma_t;
+    float ca, cb, cBh, rk_c, rho0_c, rho1_c;      // corrector
+    float pa, pb, pBh, rk_p, rho_p;               // predictor
+};
+__global__ __launch_bounds__(256) void unipc_update_kernel(const bf16_t* __restrict__ nu, const bf16_t* __restrict__ nc,
+                                                           const bf16_t* __restrict__ sample, const bf16_t* __restrict__ last,
+                                                           const bf16_t* __restrict__ m0p, const bf16_t* __restrict__ m1p,
+                                                           bf16_t* __restrict__ x0_out, bf16_t* __restrict__ samp_out,
+                                                           bf16_t* __restrict__ next_out, int64_t n, VcUnipcScalars k,
+                                                           int flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool do_cfg = flags & 1, use_corr = flags & 2, corr2 = flags & 4, pred2 = flags & 8;
+    auto r = [](float v) { return round_bf16(v); };
+    const float c = (float)nc[i];
+    float noise = c;
+    if (do_cfg) {
+        const float u = (float)nu[i];
+        noise = r(u + r(k.guidance * r(c - u)));
+    }
+    const float s = (float)sample[i];
+    const float x0 = r(s - r(k.sigma_t * noise));
+    float samp = s;
+    float m0 = 0.f;
+    if (use_corr || pred2) m0 = (float)m0p[i];
+    if (use_corr) {
+        const float xt_ = r(r(k.ca * (float)last[i]) - r(k.cb * m0));
+        const float e = r(k.rho1_c * r(x0 - m0));
+        float inner = e;
+        if (corr2) inner = r(r(k.rho0_c * r(r((float)m1p[i] - m0) / k.rk_c)) + e);
+        samp = r(xt_ - r(k.cBh * inner));
+    }
+    const float xp_ = r(r(k.pa * samp) - r(k.pb * x0));
+    float nxt = xp_;
+    if (pred2) nxt = r(xp_ - r(k.pBh * r(k.rho_p * r(r(m0 - x0) / k.rk_p))));
+    x0_out[i] = (bf16_t)x0;
+    if (samp_out) samp_out[i] = (bf16_t)samp;
+    next_out[i] = (bf16_t)nxt;
+}
+
 }  // namespace
 
 int vc_launch_patchify(const void* x, void* A, int B, int C, int T, int H, int W, int Lrows, int tok_offset,
@@ -293,5 +340,23 @@ int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, v
     else
         hipLaunchKernelGGL(geoada_context_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)z,
                            (const bf16_t*)mask, (bf16_t*)out, T, h, w, F, scale);
+    return ok();
+}
+
+int vc_launch_unipc_update(const void* noise_uncond, const void* noise_cond, const void* sample, const void* last,
+                           const void* m0, const void* m1, void* x0_out, void* samp_out, void* next_out, int64_t n,
+                           const float* sc, int flags, hipStream_t st) {
+    if (!noise_cond || !sample || !x0_out || !next_out || !sc || n <= 0) return VC_E_INVALID;
+    if ((flags & 1) && !noise_uncond) return VC_E_INVALID;
+    if ((flags & 2) && (!last || !m0)) return VC_E_INVALID;
+    if ((flags & 4) && (!(flags & 2) || !m1)) return VC_E_INVALID;
+    if ((flags & 8) && !m0) return VC_E_INVALID;
+    VcUnipcScalars k;
+    k.guidance = sc[0]; k.sigma_t = sc[1];
+    k.ca = sc[2]; k.cb = sc[3]; k.cBh = sc[4]; k.rk_c = sc[5]; k.rho0_c = sc[6]; k.rho1_c = sc[7];
+    k.pa = sc[8]; k.pb = sc[9]; k.pBh = sc[10]; k.rk_p = sc[11]; k.rho_p = sc[12];
+    hipLaunchKernelGGL(unipc_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const bf16_t*)noise_uncond,
+                       (const bf16_t*)noise_cond, (const bf16_t*)sample, (const bf16_t*)last, (const bf16_t*)m0,
+                       (const bf16_t*)m1, (bf16_t*)x0_out, (bf16_t*)samp_out, (bf16_t*)next_out, n, k, flags);
     return ok();
 }

@@ -89,6 +89,9 @@ int vc_launch_axpy(const void* a, const void* b, void* out, float s, int64_t n, 
 int vc_launch_sub(const void* a, const void* b, void* out, int64_t n, hipStream_t st);
 // zero-pad text rows: dst[b, i, :] = i < len[b] ? src_b[i, :] : 0      (VC.py:358-363)
 int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, hipStream_t st);
+int vc_launch_unipc_update(const void* noise_uncond, const void* noise_cond, const void* sample, const void* last,
+                           const void* m0, const void* m1, void* x0_out, void* samp_out, void* next_out, int64_t n,
+                           const float* sc, int flags, hipStream_t st);
 int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F,
                              hipStream_t st);
 // Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py):

@@ -150,3 +150,29 @@ def geoada_context(z, mask):
         raise ValueError(f"geoada_context: mask {tuple(mask.shape)} does not map onto latents {tuple(z.shape)} "
                          "(needs T = (F+3)//4, H = 8h, W = 8w, h and w even; PIPE.py:459-466)")
     return out
+
+
+def unipc_update(noise_pred, sample, scalars, flags, last=None, m0=None, m1=None, want_sample=True):
+    """Fused CFG combine + flow x0 + UniPC corrector + predictor (include/vcengine.h: vc_op_unipc_update).
+    noise_pred: [2, ...] (uncond, cond) when flags & 1 else [1, ...] / [...]; returns (x0, corrected sample or None, next)."""
+    lib = _lib.load()
+    _chk(noise_pred, "noise_pred"); _chk(sample, "sample"); _chk(last, "last"); _chk(m0, "m0"); _chk(m1, "m1")
+    n = sample.numel()
+    noise_pred = noise_pred.contiguous()
+    if flags & 1:
+        assert noise_pred.numel() == 2 * n
+        nu, nc = noise_pred.view(2, -1)[0], noise_pred.view(2, -1)[1]
+    else:
+        assert noise_pred.numel() == n
+        nu, nc = None, noise_pred.view(-1)
+    sample = sample.contiguous()
+    x0 = torch.empty_like(sample)
+    nxt = torch.empty_like(sample)
+    samp = torch.empty_like(sample) if (want_sample and flags & 2) else None
+    sc = (C.c_float * 13)(*[float(v) for v in scalars])
+    cont = lambda t: None if t is None else t.contiguous()
+    last, m0, m1 = cont(last), cont(m0), cont(m1)
+    rc = lib.vc_op_unipc_update(_ptr(nu), _ptr(nc), _ptr(sample), _ptr(last), _ptr(m0), _ptr(m1), _ptr(x0), _ptr(samp),
+                                _ptr(nxt), n, sc, int(flags), _stream())
+    _lib.check(rc)
+    return x0, samp, nxt

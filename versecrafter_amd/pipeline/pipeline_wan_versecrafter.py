@@ -137,6 +137,10 @@ class WanVerseCrafterPipeline:
         noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
                                       geoada_context=geoada_context_input, seq_len=seq_len,
                                       geoada_context_scale=geoada_context_scale)
+        if (hasattr(self.scheduler, "step_cfg") and latents.is_cuda and latents.dtype == torch.bfloat16 and
+                noise_pred.dtype == torch.bfloat16 and (not do_cfg or noise_pred.shape[0] == 2 * latents.shape[0])):
+            # CFG combine + x0 + UniPC corrector / predictor in one HIP kernel; bit-identical to the two steps below
+            return self.scheduler.step_cfg(noise_pred, t, latents, self.guidance_scale if do_cfg else None)
         if do_cfg:
             noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
             noise_pred = noise_pred_uncond + self.guidance_scale * (noise_pred_text - noise_pred_uncond)

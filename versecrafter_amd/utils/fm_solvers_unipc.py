@@ -188,5 +188,80 @@ class FlowUniPCMultistepScheduler:
             return (prev_sample,)
         return {"prev_sample": prev_sample}
 
+    # -- fused device path (libvcengine: vc_op_unipc_update) --------------------------------------------
+    def _corr_scalars(self, order: int, dtype):
+        """The scalars `_correct` multiplies tensors with, computed by the same 0-dim fp32 tensor arithmetic."""
+        sigma_t, sigma_s0 = self.sigmas[self._step_index], self.sigmas[self._step_index - 1]
+        alpha_t = 1 - sigma_t
+        h = self._lambda(sigma_t) - self._lambda(sigma_s0)
+        rks = []
+        for i in range(1, order):
+            rks.append((self._lambda(self.sigmas[self._step_index - (i + 1)]) - self._lambda(sigma_s0)) / h)
+        rk = float(rks[0]) if rks else 1.0
+        rks.append(torch.tensor(1.0))
+        rks = torch.stack([torch.as_tensor(r, dtype=torch.float32) for r in rks])
+        R, b, h_phi_1, B_h = self._coeffs(order, rks, -h)
+        rhos_c = torch.tensor([0.5], dtype=dtype) if order == 1 else torch.linalg.solve(R, b).to(dtype)
+        return (float(sigma_t / sigma_s0), float(alpha_t * h_phi_1), float(alpha_t * B_h), rk, float(rhos_c[0]),
+                float(rhos_c[-1]))
+
+    def _pred_scalars(self, order: int):
+        sigma_t, sigma_s0 = self.sigmas[self._step_index + 1], self.sigmas[self._step_index]
+        alpha_t = 1 - sigma_t
+        h = self._lambda(sigma_t) - self._lambda(sigma_s0)
+        rk = 1.0
+        if order == 2:
+            rk = float((self._lambda(self.sigmas[self._step_index - 1]) - self._lambda(sigma_s0)) / h)
+        elif order > 2:
+            raise NotImplementedError("fused UniPC update: solver_order <= 2 (the Wan configuration)")
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        B_h = hh if self.config.solver_type == "bh1" else torch.expm1(hh)
+        return float(sigma_t / sigma_s0), float(alpha_t * h_phi_1), float(alpha_t * B_h), rk, 0.5
+
+    def step_cfg(self, noise_pred: torch.Tensor, timestep, sample: torch.Tensor, guidance_scale: Optional[float] = None):
+        """`step` preceded by the classifier-free-guidance combine of PIPE.py:903-906, as ONE HIP kernel over the latent
+        (bf16 CUDA tensors only).  noise_pred: [2B, ...] = [uncond, cond] when guidance_scale is given, else [B, ...].
+        Bit-identical to `cfg combine; step()`: the kernel rounds to bf16 wherever the torch ops do.  Returns the next sample."""
+        from .. import ops
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' first")
+        if not (sample.is_cuda and sample.dtype == torch.bfloat16 and noise_pred.dtype == torch.bfloat16):
+            raise TypeError("step_cfg runs on bfloat16 CUDA (HIP) tensors; use step() otherwise")
+        if self.config.solver_order > 2:
+            raise NotImplementedError("fused UniPC update: solver_order <= 2 (the Wan configuration)")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        i = self._step_index
+        use_corrector = i > 0 and i - 1 not in self.disable_corrector and self.last_sample is not None
+        corr_order = self.this_order
+        flags = (1 if guidance_scale is not None else 0) | (2 if use_corrector else 0)
+        sc = [0.0 if guidance_scale is None else float(guidance_scale), float(self.sigmas[i])]
+        if use_corrector:
+            sc += list(self._corr_scalars(corr_order, sample.dtype))
+            flags |= 4 if corr_order == 2 else 0
+        else:
+            sc += [0.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+        if self.config.lower_order_final:
+            this_order = min(self.config.solver_order, len(self.timesteps) - i)
+        else:
+            this_order = self.config.solver_order
+        this_order = min(this_order, self.lower_order_nums + 1)
+        sc += list(self._pred_scalars(this_order))
+        flags |= 8 if this_order == 2 else 0
+        m_old, m_older = self.model_outputs[-1], self.model_outputs[-2]
+        x0, corrected, nxt = ops.unipc_update(noise_pred, sample, sc, flags, last=self.last_sample, m0=m_old, m1=m_older)
+        for k in range(self.config.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+            self.timestep_list[k] = self.timestep_list[k + 1]
+        self.model_outputs[-1] = x0
+        self.timestep_list[-1] = timestep
+        self.this_order = this_order
+        self.last_sample = corrected if use_corrector else sample
+        if self.lower_order_nums < self.config.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return nxt
+
     def __len__(self):
         return self.config.num_train_timesteps
