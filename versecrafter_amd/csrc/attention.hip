@@ -12,7 +12,9 @@
 //  * software pipeline inside each wave: the MFMA chain of S(t+1) = K(t+1).Q^T is issued together with the
 //    exp2 / row-sum / bf16-pack VALU work of tile t, and the O += V(t)^T.P(t)^T chain together with the row
 //    maxima of tile t+1; the loop is unrolled by two so that every LDS address is register + immediate;
-//  * online softmax is exact: O is rescaled only on tiles where some row of the wave found a new maximum;
+//  * online softmax with a deferred rescale: a row's exponent reference follows its running maximum only when the row has
+//    outgrown it by more than 2^8 (per row, so results do not depend on wave composition); O / l is unchanged by the
+//    choice of reference, the rescale of O (64 multiplies per lane) runs on a few tiles per sequence instead of ~40 %;
 //  * S^T = K . Q^T ("swapped" product): the 32x32 accumulator has the query row on the LANE and the key
 //    index in the registers, so row max / row sum are per-lane loops plus one exchange with lane^32,
 //    and the accumulator is already the B operand of the next product  O^T = V^T . P^T  (no LDS trip).
@@ -29,6 +31,10 @@
 #include "vc_kernels.h"
 
 namespace {
+
+#ifndef VC_ATTN_DEFER_MAX
+#define VC_ATTN_DEFER_MAX 8
+#endif
 
 constexpr int D = 128;
 constexpr int KT = 64;      // keys per tile
@@ -251,16 +257,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         __syncthreads();   // K(t+1), V(t) landed; all waves are past QK(t) [Kst[PAR]] and PV(t-1) [Vst[PAR^1]]
         if (t + 2 < nt) stage(t + 2, true, false, PAR, 0);
         if (MORE) stage(t + 1, false, true, 0, PAR ^ 1);
-        // rescale for the maxima found last iteration (exact: skipped when no row of the wave moved)
-        if (__any(m_new > m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            l_run *= alpha;
+        // Deferred rescale (VC_ATTN_DEFER_MAX = T > 0): a row's exponent reference m_run follows its true running maximum
+        // m_new only once the row has outgrown it by more than 2^T; until then P = exp2((S - m_run) c) may exceed 1
+        // (< 2^T: harmless in bf16 / fp32).  O and l carry the same factor, so the quotient is unchanged; only the
+        // rounding points of P move.  The decision is per row (lane), so a row's result does not depend on which other
+        // rows share its wave.  T = 0: classic form (reference follows the maximum; exact skip when no row moved).
+        {
+            const bool moved = VC_ATTN_DEFER_MAX > 0 ? (m_new - m_run) * c > (float)VC_ATTN_DEFER_MAX : m_new > m_run;
+            if (__any(moved)) {
+                const float m_ref = moved ? m_new : m_run;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_ref) * c);
+                l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+                m_run = m_ref;
+            }
         }
-        m_run = m_new;
         const float mc = m_run * c;
         // ---- phase 1: MFMA S(t+1) = K(t+1).Q^T  ||  VALU P(t) = exp2(S(t) c - m c), row sums, bf16 pack ----
         if (MORE) qk(smem + P_KST + (PAR ^ 1) * TILE_BYTES, Sn);
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             }
         if (MORE) {
             if (MASK) mask_tail(Sn, t + 1);
-            m_new = fmaxf(m_run, row_max(Sn));
+            m_new = fmaxf(m_new, row_max(Sn));       // true running maximum (>= m_run)
         }
     };
     using T_ = std::true_type;
