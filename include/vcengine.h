@@ -126,6 +126,12 @@ int vc_op_attention_segmented(const void* q, const void* k, const void* v, void*
                               const int64_t* q_strides4, const int64_t* k_strides4, const int64_t* v_strides4,
                               const int64_t* o_strides4, int seg_len, int k_len, float scale, void* stream);
 
+/* Cross-attention over a zero-padded prompt (WT.py:425-430 after VC.py:358-363): per batch b the keys pad_from[b] .. Lk-1 are
+ * IDENTICAL rows (HOST int32 array of B <= 8 entries); they are folded into one key of multiplicity Lk - pad_from[b]. */
+int vc_op_attention_padmerge(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                             const int64_t* o_strides, const int32_t* pad_from, float scale, void* stream);
+
 /* WanLayerNorm + modulate (mode 0: y = LN(x)*(1+p0[b])+p1[b]) or affine (mode 1: y = LN(x)*p0+p1). */
 int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
                     const void* p0, const void* p1, int64_t p_bstride, void* stream);

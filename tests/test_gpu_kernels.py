@@ -227,6 +227,27 @@ def test_attention_segmented_layout_equals_contiguous_bitwise(ops, S, Ls, k_len)
     assert torch.isfinite(got.float()).all() and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("lens", [(77, 60), (1, 511), (0, 512), (300, 64), (510, 129)])
+def test_cross_attention_padded_key_folding(ops, lens):
+    """T5 cross-attention attends over all 512 positions of a zero-padded prompt (WT.py:425-430): the padded K / V rows
+    are identical, and folding them into one key with multiplicity n (log2 n added to its exponent) is the same softmax.
+    Checked against plain attention over all 512 keys (kernel vs kernel, bf16 rounding only) and against the oracle."""
+    rs = np.random.RandomState(sum(lens) + 3)
+    B, H, Lq, Lk = 2, 3, 200, 512
+    q = bf(rs_randn(rs, B, Lq, H, 128))
+    k, v = bf(rs_randn(rs, B, Lk, H, 128)), bf(rs_randn(rs, B, Lk, H, 128))
+    for b, n in enumerate(lens):
+        if n < Lk:
+            k[b, n:] = k[b, n:n + 1].clone()
+            v[b, n:] = v[b, n:n + 1].clone()
+    plain = ops.attention(dev(q), dev(k), dev(v))
+    got = ops.attention_padmerge(dev(q), dev(k), dev(v), list(lens))
+    torch.cuda.synchronize()
+    want = O.attention(q.float(), k.float(), v.float(), None)
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="padmerge vs oracle")          # same bound as test_attention
+    assert rel_l2(got, want) < 6e-3 and rel_l2(got, plain.float().cpu()) < 6e-3
+
+
 def test_attention_large_logits_rescale(ops):
     """Force the online-softmax rescale: one key row far larger than the running max, late in the sequence."""
     rs = np.random.RandomState(4)

@@ -57,6 +57,8 @@ SYMBOLS = {
                              C.POINTER(_L), _I, _F, _P]),
     "vc_op_attention_segmented": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                        C.POINTER(_L), _I, _I, _F, _P]),
+    "vc_op_attention_padmerge": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
+                                      C.POINTER(_L), C.POINTER(C.c_int32), _F, _P]),
     "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
     "vc_op_geoada_context": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

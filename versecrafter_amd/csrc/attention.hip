@@ -91,7 +91,11 @@ VC_DEVICE unsigned row_byte_off(int key, int64_t ts, int seg_len, int64_t ss) {
     return (unsigned)(((int64_t)sg * ss + (int64_t)(key - sg * seg_len) * ts) * 2);
 }
 
-template <bool SEG, int NW>
+// MERGE (T5 cross-attention): the keys from pad_from[b] on are IDENTICAL rows (the reference zero-pads every prompt to 512
+// tokens before text_embedding, VC.py:358-363, and attends over all of them, WT.py:425-430): n equal keys contribute
+// n * exp(s) to numerator and denominator alike, so one of them is kept with log2(n) added to its exponent and the rest are
+// skipped -- the same softmax with 512 - len fewer keys.
+template <bool SEG, int NW, bool MERGE = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams p, int nQ, int nwork) {
     constexpr int QB = NW * 32;          // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +113,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     const bf16_t* vp = (const bf16_t*)p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
     bf16_t* op = (bf16_t*)p.out + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
 
-    const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
+    int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
+    float pad_bias = 0.f;              // added to the raw logit of key k_len - 1 (MERGE)
+    if (MERGE) {
+        const int from = p.pad_from[b];
+        if (from >= 0 && from < p.Lk - 1) {
+            k_len = from + 1;
+            pad_bias = log2f((float)(p.Lk - from)) / (p.scale * 1.4426950408889634f);
+        }
+    }
     const int nt = (k_len + KT - 1) / KT;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
     constexpr int RPW = KT / NW;                          // tile rows staged per wave (16 or 8)
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             for (int e = 0; e < 16; ++e) {
                 const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (key >= k_len) S[kb][e] = -1e30f;
+                else if (MERGE && key == k_len - 1) S[kb][e] += pad_bias;
             }
     };
     auto row_max = [&](const f32x16 (&S)[2]) -> float {
@@ -342,12 +355,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     }
 }
 
-template <bool SEG, int NW>
+template <bool SEG, int NW, bool MERGE = false>
 int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
     constexpr int QB = NW * 32;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<SEG, NW>,
+        if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<SEG, NW, MERGE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return VC_E_HIP;
         attr_set = true;
@@ -355,7 +368,7 @@ int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
     const int nQ = (p.Lq + QB - 1) / QB;
     const int nwork = p.B * p.H * nQ;
     const int grid = (nwork + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<SEG, NW>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p, nQ, nwork);
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<SEG, NW, MERGE>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p, nQ, nwork);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 
@@ -374,6 +387,10 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
     if (span_k >= (1ll << 32) || span_v >= (1ll << 32) || p.k_ts < 0 || p.v_ts < 0) return VC_E_UNSUPPORTED;
     // 256 query rows per workgroup (8 waves) halve the K/V LDS-DMA per FLOP on long sequences; short key sequences
     // (T5 cross-attention, 512 keys) are prologue-dominated and run better with twice as many, smaller workgroups
+    if (p.pad_merge) {
+        if (p.seg_len > 0 || p.k_len > 0 || p.B > 8) return VC_E_UNSUPPORTED;
+        return launch_attn_pipe<false, 4, true>(p, stream);
+    }
     if (p.Lk >= 2048) return p.seg_len > 0 ? launch_attn_pipe<true, 8>(p, stream) : launch_attn_pipe<false, 8>(p, stream);
     return p.seg_len > 0 ? launch_attn_pipe<true, 4>(p, stream) : launch_attn_pipe<false, 4>(p, stream);
 }

@@ -67,6 +67,7 @@ struct vc_engine {
         *tp_b, *head_mod, *head_w, *head_b;
 
     float2* rope_dev = nullptr;
+    int text_lens[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // prompt lengths of the prepared video (cross-attention folds the padded keys)
 
     // sequence parallel
     int P = 1, rank = 0;
@@ -345,6 +346,10 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
         a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
+        if (B <= 8 && !getenv("VC_NO_PAD_MERGE")) {             // the zero-padded prompt positions are identical K / V rows
+            a.pad_merge = 1;
+            for (int i = 0; i < B; ++i) a.pad_from[i] = h->text_lens[i];
+        }
         VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_CROSS));
         VcGemmParams g = gemm(ln.attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
         g.resid = xs; g.ldr = d;
@@ -603,6 +608,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         bw.ck = a + o_kv + (int64_t)(2 * i) * kvb;
         bw.cv = a + o_kv + (int64_t)(2 * i + 1) * kvb;
     }
+    for (int i = 0; i < 8; ++i) h->text_lens[i] = i < B ? text_lens[i] : 0;
     h->B = B; h->T = T; h->H = H; h->W = Wd; h->H2 = H / 2; h->W2 = Wd / 2; h->L = L; h->Lpad = Lpad; h->Lloc = Lloc;
     h->M = M; h->tok_off = h->rank * Lloc; h->have_residual = false;
 
@@ -835,6 +841,22 @@ int vc_op_attention_segmented(const void* q, const void* k, const void* v, void*
     a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2]; a.v_ss = vs[3];
     a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2]; a.o_ss = os[3];
     a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.k_len = k_len; a.scale = scale; a.seg_len = seg_len;
+    return vc_launch_attention(a, (hipStream_t)stream);
+}
+
+int vc_op_attention_padmerge(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                             const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os,
+                             const int32_t* pad_from, float scale, void* stream) {
+    if (!qs || !ks || !vs || !os || !pad_from || B <= 0 || B > 8) return VC_E_INVALID;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = 0; a.scale = scale;
+    a.pad_merge = 1;
+    for (int i = 0; i < B; ++i) a.pad_from[i] = pad_from[i];
     return vc_launch_attention(a, (hipStream_t)stream);
 }
 

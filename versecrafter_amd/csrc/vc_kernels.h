@@ -53,6 +53,10 @@ struct VcAttnParams {
     // (t / seg_len) * *_ss + (t % seg_len) * *_ts ; seg_len == 0 -> plain t * *_ts
     int seg_len;
     int64_t q_ss, k_ss, v_ss, o_ss;
+    // identical trailing keys (zero-padded prompt positions): per batch b the keys pad_from[b] .. Lk-1 are equal rows and are
+    // folded into one key with multiplicity Lk - pad_from[b]  (pad_merge != 0; B <= 8; pad_from[b] < 0 or >= Lk-1: nothing to fold)
+    int pad_merge;
+    int pad_from[8];
 };
 int vc_launch_attention(const VcAttnParams& p, hipStream_t stream);
 

@@ -65,6 +65,25 @@ def attention(q, k, v, k_len=0, scale=None, out=None):
     return out
 
 
+def attention_padmerge(q, k, v, pad_from, scale=None):
+    """attention() where, per batch b, the keys pad_from[b] .. Lk-1 are identical rows (zero-padded prompt positions):
+    they are folded into one key with multiplicity Lk - pad_from[b].  Same result as attention(q, k, v) up to rounding."""
+    lib = _lib.load()
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and len(pad_from) == B
+    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    st = lambda t: _lib.i64x3(t.stride(0), t.stride(1), t.stride(2))
+    pf = (C.c_int32 * B)(*[int(v_) for v_ in pad_from])
+    rc = lib.vc_op_attention_padmerge(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out), pf,
+                                      float(scale), _stream())
+    _lib.check(rc)
+    return out
+
+
 def attention_segmented(q, k, v, k_len=0, scale=None):
     """Attention on the Ulysses receive layout: q, k, v [S, B, Lseg, H, 128] (segment s holds tokens s*Lseg .. of the
     sequence) -> out in the same layout.  Equivalent to attention() on the [B, S*Lseg, H, 128] concatenation."""
