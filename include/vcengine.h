@@ -51,6 +51,9 @@ typedef struct vc_config {
 #define VC_FWD_RUN_MAIN_BLOCKS 1u   /* run self.blocks (should_calc)                         */
 #define VC_FWD_STORE_RESIDUAL 2u    /* keep x_out - x_in  (previous_residual_cond)           */
 #define VC_FWD_USE_RESIDUAL 4u      /* x = x + previous_residual instead of the main blocks */
+#define VC_FWD_SHARED_CFG_INPUT 8u  /* caller asserts: every sample has the SAME x, t and geoada_context (the CFG pair of
+                                       PIPE.py:878-887 differs only in the prompt): block 0 of both chains computes its
+                                       self-attention half once; results are bit-identical to the unflagged call */
 
 int vc_abi_version(void);
 const char* vc_last_error(const vc_engine* h);     /* h may be NULL: last error of a failed vc_create */

@@ -122,6 +122,32 @@ def test_enable_riflex_reaches_the_engine_and_is_reversible(fwd):
     assert torch.equal(run(m, fwd, seq_len), base)
 
 
+def test_shared_cfg_prefix_is_bit_identical(model, fwd, monkeypatch):
+    """The sampler's CFG pair (PIPE.py:878-887) duplicates latents, timestep and control maps; the engine then computes the
+    prompt-independent prefix of block 0 of both chains once (VC_FWD_SHARED_CFG_INPUT).  Detected from the tensors, and the
+    result must equal the full computation bit for bit; different samples must not take the shortcut."""
+    from versecrafter_amd import _lib
+    seq_len = int(fwd["A.seq_len"])
+    x = fwd["A.x"][:1].repeat(2, 1, 1, 1, 1)
+    geo = fwd["A.geoada"][:1].repeat(2, 1, 1, 1, 1).bfloat16().cuda()
+    t = fwd["A.t"][:1].repeat(2)
+    ctx = [fwd["A.ctx0"].bfloat16().cuda(), fwd["A.ctx1"].bfloat16().cuda()]
+    fast = model(x.bfloat16().cuda(), t.cuda(), geo, ctx, seq_len)
+    assert model._last_flags & _lib.VC_FWD_SHARED_CFG_INPUT
+    monkeypatch.setenv("VC_NO_SHARED_CFG", "1")
+    full = model(x.bfloat16().cuda(), t.cuda(), geo, ctx, seq_len)
+    assert not (model._last_flags & _lib.VC_FWD_SHARED_CFG_INPUT)
+    monkeypatch.delenv("VC_NO_SHARED_CFG")
+    torch.cuda.synchronize()
+    assert torch.equal(fast, full) and not torch.equal(fast[0], fast[1])          # the prompts differ
+    run(model, fwd, seq_len)                                                       # golden inputs: the samples differ
+    assert not (model._last_flags & _lib.VC_FWD_SHARED_CFG_INPUT)
+    x2 = x.clone()
+    x2[1, 0, 0, 0, 0] += 1.0
+    model(x2.bfloat16().cuda(), t.cuda(), geo, ctx, seq_len)
+    assert not (model._last_flags & _lib.VC_FWD_SHARED_CFG_INPUT)
+
+
 def test_cfg_skip_runs_conditional_half_only(model, fwd):
     """cfg_skip (third-party decorator bound at WT.py:850-871; CLI.py:313): for the last `ratio` of the steps only the
     conditional half is computed and returned twice."""

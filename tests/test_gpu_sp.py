@@ -102,15 +102,19 @@ def make_model(weights):
     return m.to(torch.bfloat16).to("cuda")
 
 
-@pytest.mark.parametrize("P,seq_len", [(2, 72), (4, 72), (2, 75)])
-def test_sp_equals_single_rank_bitwise(P, seq_len):
-    """seq_len 75 -> padded to 76 for P=2 (WT.py:195-196): compared against SP(1) run at seq_len 76."""
+@pytest.mark.parametrize("P,seq_len,cfg_pair", [(2, 72, False), (4, 72, False), (2, 75, False), (2, 72, True), (4, 75, True)])
+def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair):
+    """seq_len 75 -> padded to 76 for P=2 (WT.py:195-196): compared against SP(1) run at seq_len 76.
+    cfg_pair: both samples carry the same latent / control maps (the sampler's CFG pair): the shared block-0 prefix of the
+    engine is active on every rank and in the single-rank reference."""
     cfg = O.Config(**TINY)
     W = O.random_weights(cfg, 11)
     g = torch.Generator().manual_seed(1)
     T, h, w = 3, 8, 12
     x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
     geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    if cfg_pair:
+        x[1], geo[1] = x[0], geo[0]
     ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
     t = torch.tensor([640.0, 640.0]).cuda()
 

@@ -251,9 +251,9 @@ int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, fl
 }
 
 // self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into ln.attn
-int self_attention(vc_engine* h, Lane& ln) {
+int self_attention(vc_engine* h, Lane& ln, int B) {
     hipStream_t s = ln.s;
-    const int d = h->cfg.dim, N = h->cfg.num_heads, B = h->B, Lloc = h->Lloc, P = h->P;
+    const int d = h->cfg.dim, N = h->cfg.num_heads, Lloc = h->Lloc, P = h->P;
     VcAttnParams a;
     memset(&a, 0, sizeof a);
     a.scale = 1.0f / sqrtf(128.0f);
@@ -297,20 +297,25 @@ int self_attention(vc_engine* h, Lane& ln) {
 
 // WanAttentionBlock.forward (WT.py:564-611) on stream buffer xs, in place.  hint (optional): VC.py:146-147.
 // wait_hint / done: optional events -- wait on the lane stream right before the FFN-2 GEMM that reads `hint`, record after it.
+// shared_sa: the samples of the batch enter the block with IDENTICAL rows, modulation and RoPE (first block of either chain
+// when the CFG pair carries the same latent, timestep and control maps, PIPE.py:878-887): the self-attention half -- all of
+// the block up to the first use of the prompt -- is computed for sample 0 only and its rows are copied to the other samples.
+// Bit-identical to computing every sample (every output row is the same sequence of operations on the same numbers).
 int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, Lane& ln,
-              hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr) {
+              hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr, bool shared_sa = false) {
     hipStream_t s = ln.s;
     const int d = h->cfg.dim, f = h->cfg.ffn_dim, M = h->M, B = h->B, Lloc = h->Lloc, TL = h->cfg.text_len;
+    const int Bs = shared_sa ? 1 : B, Ms = Bs * Lloc;          // batch / rows of the self-attention half
     const float eps = h->cfg.eps;
     const char* mod = (const char*)ln.mod;
     auto modp = [&](int j) { return (const void*)(mod + (int64_t)j * d * 2); };
     // e = modulation + e0  (WT.py:588)
     VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, ln.mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, Ms, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
     // q, k, v projections into [M, 3d]  (WT.py:385-387): one grouped launch (3 problems sharing A)
     {
-        VcGemmParams g = gemm(ln.tb, d, w.sa_q_w, w.sa_q_b, ln.qkv, 3 * d, M, d, d);
+        VcGemmParams g = gemm(ln.tb, d, w.sa_q_w, w.sa_q_b, ln.qkv, 3 * d, Ms, d, d);
         g.ngroups = 3;
         g.Wg[0] = w.sa_k_w; g.biasg[0] = w.sa_k_b; g.Cg[0] = (char*)ln.qkv + (int64_t)d * 2;
         g.Wg[1] = w.sa_v_w; g.biasg[1] = w.sa_v_b; g.Cg[1] = (char*)ln.qkv + (int64_t)2 * d * 2;
@@ -318,18 +323,21 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     }
     // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, 3 * d, M, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)ln.qkv + (int64_t)d * 2, 3 * d, M, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, 3 * d, Ms, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)ln.qkv + (int64_t)d * 2, 3 * d, Ms, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
     {
-        int r = self_attention(h, ln);
+        int r = self_attention(h, ln, Bs);
         if (r != VC_OK) return r;
     }
     // x = x + o(attn) * e2  (WT.py:404, 595)
     {
-        VcGemmParams g = gemm(ln.attn, d, w.sa_o_w, w.sa_o_b, xs, d, M, d, d, VC_EPI_BIAS_GATE_RESID);
+        VcGemmParams g = gemm(ln.attn, d, w.sa_o_w, w.sa_o_b, xs, d, Ms, d, d, VC_EPI_BIAS_GATE_RESID);
         g.resid = xs; g.ldr = d; g.gate = modp(2); g.gate_bstride = 6 * d; g.rows_per_batch = Lloc;
         VCCHK(h, p_gemm(h, g, s));
     }
+    if (shared_sa)
+        for (int b = 1; b < B; ++b)
+            HIPCHK(h, hipMemcpyAsync((char*)xs + (int64_t)b * Lloc * d * 2, xs, (int64_t)Lloc * d * 2, hipMemcpyDeviceToDevice, s));
     // cross attention: x = x + o(attn(rms(q(norm3(x))), K, V))  (WT.py:600, 410-436)
     { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s)); }
     {
@@ -660,6 +668,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     if (!h->prepared) return fail(h, VC_E_STATE, "vc_forward before vc_prepare_video");
     const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL,
                use_res = flags & VC_FWD_USE_RESIDUAL;
+    const bool shared0 = (flags & VC_FWD_SHARED_CFG_INPUT) && h->B >= 2;   // see run_block(shared_sa)
     if (run_main == use_res) return fail(h, VC_E_INVALID, "vc_forward: exactly one of RUN_MAIN_BLOCKS / USE_RESIDUAL");
     if (use_res && !h->have_residual) return fail(h, VC_E_STATE, "vc_forward: no stored residual to re-use");
     hipStream_t s = (hipStream_t)stream;
@@ -686,7 +695,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
         auto adapter_block = [&](int n, Lane& la, int nslots) -> int {
             const BlockW& gb = h->gblocks[n];
-            int r = run_block(h, gb, h->c, nullptr, 0.f, la);
+            int r = run_block(h, gb, h->c, nullptr, 0.f, la, nullptr, nullptr, shared0 && n == 0);
             if (r != VC_OK) return r;
             VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint[n % nslots], d, M, d, d);
             VCCHK(h, p_gemm(h, g, la.s));
@@ -709,7 +718,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                         if (r != VC_OK) return r;
                         ++next_adapter;
                     }
-                int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint[0] : nullptr, geoada_context_scale, L0);
+                int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint[0] : nullptr, geoada_context_scale, L0, nullptr,
+                                  nullptr, shared0 && i == 0);
                 if (r != VC_OK) return r;
             }
         } else {
@@ -742,11 +752,11 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                 if (hn >= 0) {
                     while (issued <= hn) { int r = issue_adapter(issued); if (r != VC_OK) return r; ++issued; }
                     int r = run_block(h, h->blocks[i], h->x, h->hint[hn % 2], geoada_context_scale, L0, h->ev_hint[hn],
-                                      h->ev_used[hn]);
+                                      h->ev_used[hn], shared0 && i == 0);
                     if (r != VC_OK) return r;
                     if (issued < NA && issued <= hn + 2) { r = issue_adapter(issued); if (r != VC_OK) return r; ++issued; }
                 } else {
-                    int r = run_block(h, h->blocks[i], h->x, nullptr, geoada_context_scale, L0);
+                    int r = run_block(h, h->blocks[i], h->x, nullptr, geoada_context_scale, L0, nullptr, nullptr, shared0 && i == 0);
                     if (r != VC_OK) return r;
                 }
             }

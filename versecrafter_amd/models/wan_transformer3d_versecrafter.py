@@ -428,6 +428,14 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             else:
                 flags = _lib.VC_FWD_USE_RESIDUAL
         xc = x.contiguous()
+        # CFG pair of the reference's sampler (PIPE.py:878-887: latents, timestep and control maps duplicated, prompts differ):
+        # the engine then computes the prompt-independent prefix of block 0 of both chains once (bit-identical result).
+        # Detected, not assumed: three device comparisons, one host readback per step.
+        if (B >= 2 and (flags & _lib.VC_FWD_RUN_MAIN_BLOCKS) and not os.environ.get("VC_NO_SHARED_CFG") and
+                bool(((xc[1:] == xc[:1]).all() & (tf[1:] == tf[:1]).all() &
+                      (geoada_context[1:] == geoada_context[:1]).all()).item())):
+            flags |= _lib.VC_FWD_SHARED_CFG_INPUT
+        self._last_flags = flags                 # introspection for tests
         out = torch.empty(B, self.out_dim, T, H, W, dtype=torch.bfloat16, device=x.device)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         with torch.cuda.device(x.device):
