@@ -49,6 +49,20 @@ def step_flops(d, ffn, NL, NA, L, B=2, text_len=512, text_dim=4096):
     return B * ((NL + NA) * f_blk + (NA + 1) * 2 * L * d * d + f_embed)
 
 
+def skipped_flops(d, NL, NA, L, B, text_lens, text_len=512, text_dim=4096):
+    """FLOPs of the algorithmic count (step_flops: the work as the reference performs it) that the engine does NOT execute per
+    step because they are output-neutral: (1) step-invariant hoists (text embedding, control-map patch embedding, the
+    cross-attention K / V projections: SURVEY 8d), (2) the identical zero-padded prompt keys of cross-attention folded into one
+    key (64-key tiles), (3) the prompt-independent half of block 0 of both chains computed once for the CFG pair."""
+    hoisted = B * ((NL + NA) * 4 * text_len * d * d + 2 * L * 512 * d + 2 * text_len * text_dim * d + 2 * text_len * d * d)
+    folded = 0
+    for n in text_lens:
+        lk_eff = min(text_len, -(-(n + 1) // 64) * 64) if n < text_len - 1 else text_len
+        folded += (NL + NA) * 4 * L * (text_len - lk_eff) * d
+    shared = (B - 1) * 2 * (8 * L * d * d + 4 * L * L * d) if B >= 2 else 0
+    return hoisted + folded + shared
+
+
 def cpu_baseline(mk, f_step):
     """Oracle timed on the host cores on a bounded sample; extrapolated to steps/s by algorithmic FLOPs."""
     from oracle import wan_oracle as O
@@ -215,6 +229,9 @@ def main():
                        "cfg": "batched pair", "guidance_scale": 5.0, "sampler": "UniPC shift 16",
                        "teacache": "off", "parallelism": f"ulysses-sp{world}", "pflop_per_step": f_step / 1e15},
             "step_mfma_frac": f_step * sps / (world * PEAK_BF16_TFLOPS * 1e12),
+            # the same with the output-neutral work the engine skips taken out of the numerator (see skipped_flops)
+            "step_mfma_frac_executed": (f_step - skipped_flops(mk["dim"], NL, NA, L, 2, (n_un, n_co), mk.get("text_len", 512),
+                                                               text_dim)) * sps / (world * PEAK_BF16_TFLOPS * 1e12),
             "outputs_finite": finite,
         }
         if prof is not None:
