@@ -115,6 +115,22 @@ def test_gemm_strided_output(ops):
     assert_bf16_close(out, want, ulps=1.01, atol=2e-3, what="strided")
 
 
+def test_gemm_dispatch_random_shapes(ops):
+    """Auto dispatch (tile=0: 128x128 / 256x256 2-stage / ping-pong by shape) over random ragged shapes around the
+    dispatch thresholds (M = 1024, N % 256, K % 128): every shape must match the oracle."""
+    rs = np.random.RandomState(2024)
+    shapes = [(1, 4, 64), (1023, 256, 128), (1024, 256, 128), (1025, 252, 192), (1024, 260, 64), (1536, 512, 320),
+              (2049, 768, 128), (777, 1024, 1024), (3000, 64, 64)]
+    for _ in range(12):
+        shapes.append((int(rs.randint(1, 2600)), 4 * int(rs.randint(1, 200)), 64 * int(rs.randint(1, 12))))
+    for (M, N, K) in shapes:
+        a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
+        ap = _padded_rows(a)                   # readable to the next 256 rows, as the engine's buffers are
+        got = ops.gemm(ap, dev(w), dev(b))
+        torch.cuda.synchronize()
+        assert_bf16_close(got, O.linear(a.float(), w.float(), b.float()), ulps=1.01, atol=2e-3, what=f"gemm {M}x{N}x{K}")
+
+
 def _padded_rows(t, mult=256):
     """Device copy of t [M, K] inside a buffer whose rows run to the next multiple of `mult` (the ping-pong kernel
     reads, never stores, those rows); the pad is filled with NaN to prove it cannot leak into stored rows."""

@@ -162,3 +162,21 @@ def test_pipeline_input_checks():
     with pytest.raises(RuntimeError):        # no T5 here: prompts need embeddings
         pipe(prompt="a cat", height=64, width=96, geoada_latents=[torch.zeros(64, 1, 8, 12)],
              mask_latents=[torch.zeros(64, 1, 8, 12)], output_type="latent")
+
+
+def test_bench_flop_accounting_matches_survey_8d():
+    """bench.py's algorithmic FLOPs per denoise step (the numerator of the roofline fractions) against SURVEY 8d / Appendix B:
+    cfg-2 2.5423, cfg-3 5.1075, cfg-4 19.737 PFLOP; the output-neutral work the engine skips is a small, positive part."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vc_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for L, want in ((20280, 2.5423), (32760, 5.1075), (75600, 19.737)):
+        got = b.step_flops(5120, 13824, 40, 20, L) / 1e15
+        assert abs(got - want) < 5e-4 * want, (L, got, want)
+    f = b.step_flops(5120, 13824, 40, 20, 32760)
+    sk = b.skipped_flops(5120, 40, 20, 32760, 2, (60, 77))
+    assert 0.015 * f < sk < 0.025 * f
+    assert b.skipped_flops(5120, 40, 20, 32760, 2, (512, 512)) < sk          # nothing to fold when the prompts are full
+    assert set(b.WORKLOADS) >= {"wan14b-81f-480x832", "wan14b-49f-480x832", "wan14b-81f-720x1280", "wan1.3b-9f-320x512", "tiny"}
