@@ -27,7 +27,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, seq_len, steps, q):
+WIDE = dict(dim=1536, ffn_dim=2048, num_heads=12, num_layers=2, text_dim=64, text_len=64,
+            geoada_in_dim=128, in_dim=16, out_dim=16, freq_dim=256)
+
+
+def _worker(rank, world, port, seq_len, steps, q, wide=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")                           # both ranks share cuda:0
@@ -38,17 +42,18 @@ def _worker(rank, world, port, seq_len, steps, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         vdist.set_multi_gpus_devices(world, 1)
-        cfg = O.Config(**TINY)
+        dims = WIDE if wide else TINY
+        cfg = O.Config(**dims)
         W = O.random_weights(cfg, 11)
         g = torch.Generator().manual_seed(1)
-        T, h, w = 3, 8, 12
+        T, h, w = (3, 40, 62) if wide else (3, 8, 12)
         x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
         geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
         ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
         t = torch.tensor([640.0, 640.0]).cuda()
 
         def make():
-            m = VerseCrafterWanTransformer3DModel(**TINY)
+            m = VerseCrafterWanTransformer3DModel(**dims)
             m.load_state_dict(W)
             return m.to(torch.bfloat16).to("cuda")
 
@@ -71,13 +76,16 @@ def _worker(rank, world, port, seq_len, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seq_len", [72, 75])
-def test_two_process_sp_equals_single_rank_bitwise(seq_len):
+@pytest.mark.parametrize("seq_len,wide", [(72, False), (75, False), (1860, True)])
+def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide):
+    """wide: 1.3B width, 1860 tokens -> 930 per rank (not a multiple of the 4-row staging pieces): the ping-pong GEMM
+    (M = 1860 >= 1024), the segmented attention's scalar-addressed fast path with pieces straddling the rank boundary, the
+    pack / unpack kernels and both engine lanes, across two processes."""
     world = 2
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, seq_len, 2, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, seq_len, 2, q, wide)) for r in range(world)]
     for p in procs:
         p.start()
     try:
