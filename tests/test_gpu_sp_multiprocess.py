@@ -76,12 +76,11 @@ def _worker(rank, world, port, seq_len, steps, q, wide=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seq_len,wide", [(72, False), (75, False), (1860, True)])
-def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide):
+@pytest.mark.parametrize("seq_len,wide,world", [(72, False, 2), (75, False, 2), (1860, True, 2), (1860, True, 4)])
+def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide, world):
     """wide: 1.3B width, 1860 tokens -> 930 per rank (not a multiple of the 4-row staging pieces): the ping-pong GEMM
     (M = 1860 >= 1024), the segmented attention's scalar-addressed fast path with pieces straddling the rank boundary, the
-    pack / unpack kernels and both engine lanes, across two processes."""
-    world = 2
+    pack / unpack kernels and both engine lanes, across two (or four: 465 tokens per rank, 3 heads each) processes."""
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = _free_port()
