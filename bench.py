@@ -26,9 +26,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 WORKLOADS = {
@@ -65,6 +62,7 @@ def skipped_flops(d, NL, NA, L, B, text_lens, text_len=512, text_dim=4096):
 
 def cpu_baseline(mk, f_step):
     """Oracle timed on the host cores on a bounded sample; extrapolated to steps/s by algorithmic FLOPs."""
+    import torch
     from oracle import wan_oracle as O
     d, ffn, heads = mk["dim"], mk["ffn_dim"], mk["num_heads"]
     text_len = mk.get("text_len", 512)
@@ -98,7 +96,7 @@ def cpu_baseline(mk, f_step):
             "host_cpus": os.cpu_count()}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -107,10 +105,79 @@ def main():
     ap.add_argument("--num_inference_steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl (= RCCL; product: the engine's own communicators over xGMI) or gloo: a REHEARSAL of the N > 1 "
+                         "launch on a box with fewer GPUs than ranks -- ranks share devices round-robin, exchange buffers are "
+                         "staged through host memory; the rate it prints is not a result")
     ap.add_argument("--teacache-steps", type=int, default=0,
                     help="also time N sampler steps from step 0 with TeaCache on (CLI defaults: threshold 0.10, skip-start 5) "
                          "and report them as a separate 'teacache_on' object; 0 = off (the headline metric is TeaCache-off)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start N fresh rank
+    processes -- one per GPU, torchrun's environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as the reference's
+    `torchrun --nproc-per-node=N` of inference.sh:62-71 -- wait for them and forward rank 0's single JSON line.
+    This parent never touches the GPU (it does not even import torch); a failed rank ends the run with its exit code."""
+    import subprocess
+    import tempfile
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs, out0 = [], tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's intra-node transport needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    rc, deadline = 0, None
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+                deadline = time.time() + 20.0                     # peers blocked in a collective never return by themselves
+        if deadline is not None and time.time() > deadline:
+            for r in live:
+                procs[r].kill()                                   # exactly the children started above
+            deadline = None
+        time.sleep(0.05)
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} lines, expected exactly one", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
 
     # Only the JSON line may reach stdout: RCCL prints a version banner on stdout when the first communicator is
     # created, other libraries may chatter too.  Route fd 1 to stderr for the whole run and keep the real stdout aside.
@@ -122,13 +189,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local = local % max(1, torch.cuda.device_count())          # ranks share devices (device_count does not initialise HIP)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("VC_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the N>1 plumbing at N=1
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        # host-side group (gloo): rendezvous, barrier, max-over-ranks of the time, shipping the ncclUniqueIds.  The data
+        # path's RCCL communicators belong to the engine (vc_sp_init_rccl); torch's own "nccl" backend is registered for
+        # CUDA tensors so that SequenceParallel recognises an RCCL-capable world, but no torch collective runs on it.
+        dist.init_process_group("gloo" if rehearsal else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
     from versecrafter_amd.pipeline import WanVerseCrafterPipeline
@@ -147,7 +220,7 @@ def main():
     if use_dist:
         from versecrafter_amd import dist as vdist
         vdist._SP_GROUP = dist.group.WORLD
-        model.enable_multi_gpus_inference()
+        model.enable_multi_gpus_inference(vdist.SequenceParallel(dist.group.WORLD, force_exchange=(world == 1)))
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
     pipe = WanVerseCrafterPipeline(transformer=model, scheduler=scheduler)
     pipe._guidance_scale = 5.0
@@ -173,9 +246,9 @@ def main():
         return lat
 
     def barrier():
+        torch.cuda.synchronize()                                   # this rank's queue (all engine streams) has drained ...
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(torch.zeros(1))                        # ... and so has every other rank's (host-side, gloo)
 
     lat = run_steps(latents, 0, args.warmup)
     barrier()
@@ -211,9 +284,10 @@ def main():
         tea = {"value": n / el, "unit": "denoise-steps/s", "steps": n, "skipped_steps": skipped, "threshold": 0.10,
                "num_skip_start_steps": 5, "note": "random weights: gate statistics differ from the released checkpoint"}
     if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    rccl_ranks = model.sp_comm_ranks()
 
     if rank == 0:
         NL, NA = mk["num_layers"], (mk["num_layers"] + 1) // 2
@@ -233,6 +307,11 @@ def main():
             "step_mfma_frac_executed": (f_step - skipped_flops(mk["dim"], NL, NA, L, 2, (n_un, n_co), mk.get("text_len", 512),
                                                                text_dim)) * sps / (world * PEAK_BF16_TFLOPS * 1e12),
             "outputs_finite": finite,
+            # world size the engine's own RCCL communicator reports after init (ncclCommCount); 0 = no RCCL exchange ran
+            "rccl_ranks": rccl_ranks,
+            "transport": ("none (single rank)" if not use_dist else
+                          "gloo + host-staged buffers (REHEARSAL of the launch, not a result)" if rehearsal else
+                          "engine-owned RCCL communicators, one per block chain"),
         }
         if prof is not None:
             bd = {}
@@ -269,7 +348,7 @@ def main():
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if use_dist:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 

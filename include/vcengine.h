@@ -32,7 +32,7 @@ extern "C" {
 #define VC_E_NOMEM (-4)
 #define VC_E_UNSUPPORTED (-5) /* shape outside what the kernels implement            */
 
-#define VC_ABI_VERSION 1
+#define VC_ABI_VERSION 2
 #define VC_MAX_GEOADA_LAYERS 64
 
 typedef struct vc_engine vc_engine;
@@ -78,6 +78,26 @@ int vc_set_rope_table(vc_engine* h, const double* cis, int rows, int cols);
 typedef int (*vc_all_to_all_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
 typedef int (*vc_all_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes, void* stream);
 int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_gather_fn ag, void* ctx);
+
+/* The product transport for world > 1: RCCL over xGMI, owned by the engine (vc_sp_init(h, ncclUniqueId, rank,
+ * world)).  Replaces set_multi_gpus_devices + usp_attn_forward's collectives (inference/versecrafter_inference.py:180;
+ * WT.py:901-921; VC.py:432-433).  The engine creates ONE COMMUNICATOR PER BLOCK CHAIN (main blocks / GeoAdapter blocks) and
+ * enqueues every exchange on the HIP stream of the chain that needs it, so the two chains overlap each other's exchanges
+ * and nothing calls back into the host on the step path.  librccl.so.1 is bound with dlopen at the first of these calls (the
+ * instance already loaded into the process is reused; VC_RCCL_LIB overrides the path).
+ *   vc_rccl_unique_id : rank 0 fills out[128] (ncclGetUniqueId); the host ships the bytes to every rank (any side channel).
+ *   vc_sp_init_rccl   : unique_ids = n_ids x 128 bytes, n_ids must be 2 (chain 0, chain 1); every rank of the world must
+ *                       call it (ncclCommInitRank is a rendezvous).  flags: VC_SP_FORCE_EXCHANGE runs the exchange path
+ *                       (pack, all-to-all, segmented attention, all-to-all, unpack, all-gather) even at world == 1.
+ *   vc_sp_comm_ranks  : ncclCommCount of chain 0's communicator (0: the RCCL transport is not active).
+ *   vc_sp_all_to_all / vc_sp_all_gather : the engine's collectives in isolation (tests): byte buffers, chain 0 or 1. */
+#define VC_RCCL_UNIQUE_ID_BYTES 128
+#define VC_SP_FORCE_EXCHANGE 1u
+int vc_rccl_unique_id(void* out, int nbytes);
+int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, int n_ids, uint32_t flags);
+int vc_sp_comm_ranks(const vc_engine* h);
+int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream);
 
 /* Step-invariant part of forward, hoisted (once per video): geoada_patch_embedding (VC.py:262-267),
  * text_embedding (VC.py:358-363) and every block's cross-attention k/v (WT.py:421-422).

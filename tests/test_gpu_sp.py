@@ -193,3 +193,61 @@ def test_collective_callbacks_on_rccl_world1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_engine_owned_rccl_exchange_world1_bitwise():
+    """The product transport (vc_sp_init_rccl: librccl bound with dlopen, two communicators, one per block chain) with a
+    1-rank world and VC_SP_FORCE_EXCHANGE: the model takes the whole N > 1 path -- q|k|v pack, ncclAllToAll on the chain's
+    stream, segmented attention, ncclAllToAll, head unpack, ncclAllGather, both chains on their own streams -- and must
+    reproduce the plain single-rank output bit for bit.  (RCCL refuses two ranks on one device; a world of 2+ needs 2+ GPUs.)"""
+    from versecrafter_amd import _lib
+    from versecrafter_amd.dist import SequenceParallel
+    cfg = O.Config(**TINY)
+    W = O.random_weights(cfg, 11)
+    g = torch.Generator().manual_seed(1)
+    T, h, w = 3, 8, 12
+    x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+    t = torch.tensor([640.0, 640.0]).cuda()
+    ref = make_model(W)(x, t, geo, ctx, 72)
+    m = make_model(W)
+    sp = SequenceParallel(None, transport="rccl", force_exchange=True)
+    assert sp.world_size == 1 and sp.transport == "rccl"
+    m.enable_multi_gpus_inference(sp)
+    for _ in range(3):
+        out = m(x, t, geo, ctx, 72)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (out.float() - ref.float()).abs().max()
+    assert m.sp_comm_ranks() == 1
+
+    # the engine's collectives in isolation, on both chains' communicators and on a side stream
+    lib, hnd = _lib.load(), m._engine
+    n = 1 << 20
+    side = torch.cuda.Stream()
+    for chain, stream in ((0, torch.cuda.current_stream()), (1, side)):
+        with torch.cuda.stream(stream):
+            send = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
+            recv = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.vc_sp_all_to_all(hnd, chain, send.data_ptr(), recv.data_ptr(), n, stream.cuda_stream), hnd)
+        stream.synchronize()
+        assert torch.equal(send, recv)
+    recv.zero_()
+    _lib.check(lib.vc_sp_all_gather(hnd, send.data_ptr(), recv.data_ptr(), n, torch.cuda.current_stream().cuda_stream), hnd)
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+
+
+def test_rccl_init_rejects_bad_arguments():
+    from versecrafter_amd import _lib
+    import ctypes as C
+    m = make_model(O.random_weights(O.Config(**TINY), 11))
+    lib, hnd = _lib.load(), m._engine_handle()
+    ids = C.create_string_buffer(256)
+    with pytest.raises(ValueError):
+        _lib.check(lib.vc_sp_init_rccl(hnd, 1, 0, ids, 1, 0), hnd)        # one id: a communicator per chain is required
+    with pytest.raises(ValueError):
+        _lib.check(lib.vc_sp_init_rccl(hnd, 2, 2, ids, 2, 0), hnd)        # rank outside the world
+    with pytest.raises(_lib.VcError):
+        _lib.check(lib.vc_sp_init_rccl(hnd, 3, 0, ids, 2, 0), hnd)        # 3 does not divide 4 heads
+    assert m.sp_comm_ranks() == 0

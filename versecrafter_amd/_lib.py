@@ -14,7 +14,9 @@ VC_OK = 0
 VC_E_INVALID, VC_E_HIP, VC_E_STATE, VC_E_NOMEM, VC_E_UNSUPPORTED = -1, -2, -3, -4, -5
 VC_FWD_RUN_MAIN_BLOCKS, VC_FWD_STORE_RESIDUAL, VC_FWD_USE_RESIDUAL, VC_FWD_SHARED_CFG_INPUT = 1, 2, 4, 8
 VC_MAX_GEOADA_LAYERS = 64
-VC_ABI_VERSION = 1
+VC_ABI_VERSION = 2
+VC_RCCL_UNIQUE_ID_BYTES = 128
+VC_SP_FORCE_EXCHANGE = 1
 
 
 class vc_config(C.Structure):
@@ -45,6 +47,11 @@ SYMBOLS = {
     "vc_missing_weights": (_I, [_P]),
     "vc_set_rope_table": (_I, [_P, C.POINTER(C.c_double), _I, _I]),
     "vc_sp_init": (_I, [_P, _I, _I, ALL_TO_ALL_FN, ALL_GATHER_FN, _P]),
+    "vc_rccl_unique_id": (_I, [_P, _I]),
+    "vc_sp_init_rccl": (_I, [_P, _I, _I, _P, _I, C.c_uint32]),
+    "vc_sp_comm_ranks": (_I, [_P]),
+    "vc_sp_all_to_all": (_I, [_P, _I, _P, _P, _L, _P]),
+    "vc_sp_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "vc_prepare_video": (_I, [_P, _P, C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _P]),
     "vc_forward": (_I, [_P, _P, _P, _P, _F, C.c_uint32, _P]),
     "vc_time_embedding": (_I, [_P, _P, _I, _P, _P]),

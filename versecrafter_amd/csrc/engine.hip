@@ -49,6 +49,7 @@ thread_local std::string g_create_error;
 // scratch buffers + stream of one block chain.  Lane 0 = main chain on the caller's stream; lane 1 = GeoAdapter chain on
 // an engine-owned stream (used when the two chains run concurrently, see vc_forward).
 struct Lane {
+    int idx = 0;
     hipStream_t s = nullptr;
     void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
 };
@@ -71,7 +72,9 @@ struct vc_engine {
 
     // sequence parallel
     int P = 1, rank = 0;
-    vc_all_to_all_fn a2a = nullptr;
+    bool sp_exchange = false;       // self-attention goes through the Ulysses exchange (P > 1; or forced at P = 1 for tests)
+    VcComm* comm[2] = {nullptr, nullptr};   // RCCL transport: one communicator per block chain (lane), vc_sp_init_rccl
+    vc_all_to_all_fn a2a = nullptr; // callback transport (vc_sp_init): tests / hosts that bring their own collective
     vc_all_gather_fn ag = nullptr;
     void* cb_ctx = nullptr;
 
@@ -250,6 +253,28 @@ int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, fl
     return VC_OK;
 }
 
+// one all-to-all / all-gather of the Ulysses exchange on the chain's own stream: the chain's own RCCL communicator, or the
+// host callbacks when the caller brought its own transport (vc_sp_init)
+int sp_all_to_all(vc_engine* h, const Lane& ln, const void* send, void* recv, int64_t bytes_per_peer, const char* what) {
+    if (h->comm[ln.idx]) {
+        if (vc_comm_all_to_all(h->comm[ln.idx], send, recv, bytes_per_peer, ln.s) != VC_OK)
+            return fail(h, VC_E_HIP, "all_to_all (%s): %s", what, vc_comm_error());
+        return VC_OK;
+    }
+    if (!h->a2a || h->a2a(h->cb_ctx, send, recv, bytes_per_peer, (void*)ln.s) != 0)
+        return fail(h, VC_E_STATE, "all_to_all callback failed (%s)", what);
+    return VC_OK;
+}
+int sp_all_gather(vc_engine* h, const Lane& ln, const void* send, void* recv, int64_t bytes) {
+    if (h->comm[ln.idx]) {
+        if (vc_comm_all_gather(h->comm[ln.idx], send, recv, bytes, ln.s) != VC_OK)
+            return fail(h, VC_E_HIP, "all_gather: %s", vc_comm_error());
+        return VC_OK;
+    }
+    if (!h->ag || h->ag(h->cb_ctx, send, recv, bytes, (void*)ln.s) != 0) return fail(h, VC_E_STATE, "all_gather callback failed");
+    return VC_OK;
+}
+
 // self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into ln.attn
 int self_attention(vc_engine* h, Lane& ln, int B) {
     hipStream_t s = ln.s;
@@ -258,7 +283,7 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
     memset(&a, 0, sizeof a);
     a.scale = 1.0f / sqrtf(128.0f);
     a.B = B;
-    if (P == 1) {
+    if (!h->sp_exchange) {
         const char* q = (const char*)ln.qkv;
         a.q = q; a.k = q + (int64_t)d * 2; a.v = q + (int64_t)2 * d * 2;
         a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * 3 * d;
@@ -274,8 +299,7 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
     const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
     VCCHK(h, vc_launch_sp_pack_qkv(ln.qkv, ln.send, B * Lloc, d, P, s));
-    if (h->a2a(h->cb_ctx, ln.send, ln.recv, 3 * blk * 2, (void*)s) != 0)
-        return fail(h, VC_E_STATE, "all_to_all callback failed (q/k/v)");
+    { int r = sp_all_to_all(h, ln, ln.send, ln.recv, 3 * blk * 2, "q/k/v"); if (r != VC_OK) return r; }
     // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
     const char* r = (const char*)ln.recv;
     a.q = r; a.k = r + blk * 2; a.v = r + 2 * blk * 2;
@@ -288,8 +312,7 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
     a.out = ln.send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
     VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
-    if (h->a2a(h->cb_ctx, ln.send, ln.recv, blk * 2, (void*)s) != 0)
-        return fail(h, VC_E_STATE, "all_to_all callback failed (o)");
+    { int r = sp_all_to_all(h, ln, ln.send, ln.recv, blk * 2, "o"); if (r != VC_OK) return r; }
     // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
     VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * Lloc, d, P, s));
     return VC_OK;
@@ -481,6 +504,7 @@ void vc_destroy(vc_engine* h) {
     for (auto e : h->ev_hint) if (e) (void)hipEventDestroy(e);
     for (auto e : h->ev_used) if (e) (void)hipEventDestroy(e);
     free_arena(h);
+    for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     if (h->rope_dev) (void)hipFree(h->rope_dev);
     if (h->small) (void)hipFree(h->small);
     delete h;
@@ -525,9 +549,53 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
     if (world > 1 && (!a2a || !ag)) return fail(h, VC_E_INVALID, "vc_sp_init: callbacks required for world > 1");
     if (h->cfg.num_heads % world)
         return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
+    for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     h->P = world; h->rank = rank; h->a2a = a2a; h->ag = ag; h->cb_ctx = ctx;
+    h->sp_exchange = world > 1;
     h->prepared = false;
     return VC_OK;
+}
+
+int vc_rccl_unique_id(void* out, int nbytes) {
+    if (!out || nbytes < VC_RCCL_UNIQUE_ID_BYTES) return fail(nullptr, VC_E_INVALID, "vc_rccl_unique_id: need %d bytes", VC_RCCL_UNIQUE_ID_BYTES);
+    int r = vc_comm_unique_id(out);
+    if (r != VC_OK) return fail(nullptr, r, "vc_rccl_unique_id: %s", vc_comm_error());
+    return VC_OK;
+}
+
+int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, int n_ids, uint32_t flags) {
+    if (!h) return VC_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, VC_E_INVALID, "vc_sp_init_rccl: bad world/rank");
+    if (!unique_ids || n_ids != 2) return fail(h, VC_E_INVALID, "vc_sp_init_rccl: two unique ids required (one communicator per chain)");
+    if (h->cfg.num_heads % world)
+        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
+    (void)hipStreamSynchronize(h->s_adp);
+    for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
+    for (int l = 0; l < 2; ++l) {                       // same order on every rank: ncclCommInitRank is a rendezvous
+        int r = vc_comm_create(&h->comm[l], (const char*)unique_ids + (size_t)l * VC_RCCL_UNIQUE_ID_BYTES, world, rank);
+        if (r != VC_OK) {
+            for (int k = 0; k < 2; ++k) { vc_comm_destroy(h->comm[k]); h->comm[k] = nullptr; }
+            return fail(h, r, "vc_sp_init_rccl (chain %d): %s", l, vc_comm_error());
+        }
+    }
+    h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr;
+    h->sp_exchange = world > 1 || (flags & VC_SP_FORCE_EXCHANGE);
+    h->prepared = false;
+    return VC_OK;
+}
+
+int vc_sp_comm_ranks(const vc_engine* h) { return h && h->comm[0] ? vc_comm_ranks(h->comm[0]) : 0; }
+
+int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, void* stream) {
+    if (!h || chain < 0 || chain > 1 || !send || !recv) return fail(h, VC_E_INVALID, "vc_sp_all_to_all: bad argument");
+    Lane ln; ln.idx = chain; ln.s = (hipStream_t)stream;
+    return sp_all_to_all(h, ln, send, recv, bytes_per_peer, "test entry");
+}
+
+int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream) {
+    if (!h || !send || !recv) return fail(h, VC_E_INVALID, "vc_sp_all_gather: bad argument");
+    Lane ln; ln.idx = 0; ln.s = (hipStream_t)stream;
+    return sp_all_gather(h, ln, send, recv, bytes);
 }
 
 int64_t vc_workspace_bytes(const vc_engine* h) { return h ? h->arena_bytes : 0; }
@@ -560,7 +628,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     const int64_t md = (int64_t)M * d * 2;
     {   // default: dual lane (adapter chain on its own stream) only under sequence parallelism; VC_DUAL_LANE=0/1 forces it
         const char* dl = getenv("VC_DUAL_LANE");
-        h->dual = dl ? atoi(dl) == 1 : (P > 1);
+        h->dual = dl ? atoi(dl) == 1 : h->sp_exchange;
     }
     const int nlanes = h->dual ? 2 : 1;
     const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md), o_x0 = take(md), o_resid = take(md);
@@ -569,7 +637,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         if (l < nlanes) {
             o_hint[l] = take(md); o_tb[l] = take(md); o_qkv[l] = take(3 * md); o_attn[l] = take(md);
             o_hb[l] = take((int64_t)M * f * 2); o_mod[l] = take((int64_t)B * 6 * d * 2);
-            o_send[l] = take(P > 1 ? 3 * md : 256); o_recv[l] = take(P > 1 ? 3 * md : 256);
+            o_send[l] = take(h->sp_exchange ? 3 * md : 256); o_recv[l] = take(h->sp_exchange ? 3 * md : 256);
         } else {
             o_hint[l] = o_hint[0]; o_tb[l] = o_tb[0]; o_qkv[l] = o_qkv[0]; o_attn[l] = o_attn[0]; o_hb[l] = o_hb[0];
             o_mod[l] = o_mod[0]; o_send[l] = o_send[0]; o_recv[l] = o_recv[0];
@@ -688,7 +756,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     { int r = time_embed(h, t, B, h->f_sin, h->f_h, h->f_e, h->f_e0, s); if (r != VC_OK) return r; }
 
     Lane& L0 = h->lane[0];
-    L0.s = s;
+    L0.idx = 0; L0.s = s;
     if (run_main) {
         if (store_res) HIPCHK(h, hipMemcpyAsync(h->x0, h->x, md, hipMemcpyDeviceToDevice, s));
         const int NA = (int)h->gblocks.size();
@@ -727,7 +795,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             // stream, at most two blocks ahead of the main layer that consumes its hints (2-slot hint ring): while one
             // chain waits for an Ulysses exchange the other chain's kernels keep the GPU busy.
             Lane& L1 = h->lane[1];
-            L1.s = h->s_adp;
+            L1.idx = 1; L1.s = h->s_adp;
             HIPCHK(h, hipEventRecord(h->ev_x, s));                       // x, e, e0 ready
             HIPCHK(h, hipStreamWaitEvent(L1.s, h->ev_x, 0));
             {
@@ -778,9 +846,9 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         VCCHK(h, p_gemm(h, g, s));
     }
     const void* y = h->ybuf;
-    if (h->P > 1) {                                          // VC.py:432-433
-        if (h->ag(h->cb_ctx, h->ybuf, h->yfull, (int64_t)M * c.out_dim * 4 * 2, (void*)s) != 0)
-            return fail(h, VC_E_STATE, "all_gather callback failed");
+    if (h->sp_exchange) {                                    // VC.py:432-433
+        int r = sp_all_gather(h, L0, h->ybuf, h->yfull, (int64_t)M * c.out_dim * 4 * 2);
+        if (r != VC_OK) return r;
         y = h->yfull;
     }
     VCCHK(h, vc_launch_unpatchify(y, out, B, c.out_dim, h->T, h->H2, h->W2, Lloc, s));

@@ -106,3 +106,14 @@ int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hip
 // generic strided 2-D copy
 int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
                            hipStream_t st);
+
+// ---- RCCL transport of the Ulysses exchange (sp_rccl.hip); librccl is bound with dlopen at first use ----
+#define VC_RCCL_UNIQUE_ID_BYTES 128
+struct VcComm;
+int vc_comm_unique_id(void* out128);
+int vc_comm_create(VcComm** out, const void* id128, int world, int rank);   // blocks until all ranks have joined
+int vc_comm_ranks(const VcComm* c);
+void vc_comm_destroy(VcComm* c);
+int vc_comm_all_to_all(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t s);
+int vc_comm_all_gather(VcComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s);
+const char* vc_comm_error();    // message of the calling thread's last failed vc_comm_* call

@@ -4,7 +4,8 @@ Stands in for the parts of the un-vendored videox_fun.dist that the reference's 
 (wan_transformer3d.py:30-32, 901-921; wan_transformer3d_versecrafter.py:269-270, 366-367, 432-433;
 inference/versecrafter_inference.py:180): group set-up, rank / world size, the head-scatter
 all-to-all around self-attention and the final all-gather.  The HIP engine packs / unpacks the exchange
-buffers itself and calls back into this module only for the collective (include/vcengine.h: vc_sp_init).
+buffers itself and runs the collectives on its own RCCL communicators (include/vcengine.h: vc_sp_init_rccl); the callback
+transport (vc_sp_init) stays for the gloo tests.
 
 Layout contract of one exchange (P ranks, B samples, Lloc = L/P local tokens, Nl = N/P local heads):
     send  [P_dst][3 (q,k,v)][B][Lloc][Nl][128]  --all_to_all-->  recv [P_src][3][B][Lloc][Nl][128]
@@ -139,21 +140,73 @@ def alias_device_bytes(ptr: int, nbytes: int, device) -> torch.Tensor:
     return torch.as_tensor(_DevBuf(ptr, nbytes), device=device)
 
 
-class SequenceParallel:
-    """Owns the callbacks handed to vc_sp_init.  The engine calls them from inside vc_forward with raw
-    pointers into its workspace; they are aliased as uint8 torch tensors and exchanged with
-    torch.distributed on the caller's current stream."""
+def _group_has_rccl(group) -> bool:
+    """True when the group's device backend is torch's "nccl" (= RCCL on ROCm)."""
+    try:
+        return "nccl" in str(dist.get_backend_config(group))
+    except Exception:
+        return dist.get_backend(group) == "nccl"
 
-    def __init__(self, group=None):
+
+class SequenceParallel:
+    """Wires the engine's Ulysses exchange to a transport (include/vcengine.h):
+
+    "rccl"  (product, default when the group's device backend is nccl): the ENGINE owns two RCCL communicators, one per
+            block chain, and enqueues ncclAllToAll / ncclAllGather on the chain's HIP stream itself (vc_sp_init_rccl);
+            this class only ships the two ncclUniqueIds from rank 0 to the other ranks over the torch group.
+    "torch" (tests on gloo with host-staged buffers; VC_SP_TRANSPORT=torch forces it on nccl): the engine calls back into
+            this class with raw pointers into its workspace, which are aliased as uint8 torch tensors and exchanged with
+            torch.distributed on the stream the engine passes in.  On nccl each chain gets its own process group --
+            ProcessGroupNCCL runs all collectives of one group on one internal stream in issue order, so a shared group
+            would make the main chain's q|k|v exchange queue behind the adapter chain's."""
+
+    def __init__(self, group=None, transport=None, force_exchange=False):
         self.group = group if group is not None else get_sp_group()
         if self.group is None and dist.is_initialized():
             self.group = dist.group.WORLD
         self.world_size = 1 if self.group is None else dist.get_world_size(self.group)
         self.rank = 0 if self.group is None else dist.get_rank(self.group)
         self.error = None
+        self.force_exchange = bool(force_exchange)
+        if transport is None:
+            transport = os.environ.get("VC_SP_TRANSPORT") or None
+        if transport is None:
+            rccl = torch.cuda.is_available() and (self.group is None or _group_has_rccl(self.group))
+            transport = "rccl" if rccl and (self.world_size > 1 or self.force_exchange) else "torch"
+        if transport not in ("rccl", "torch"):
+            raise ValueError(f"unknown sequence-parallel transport {transport!r}")
+        self.transport = transport
         self._alias = {}
+        self._lane_of_stream = {}
+        self._lane_groups = [self.group]
+        if transport == "torch" and self.world_size > 1 and _group_has_rccl(self.group):
+            ranks = [dist.get_global_rank(self.group, i) for i in range(self.world_size)]
+            self._lane_groups.append(dist.new_group(ranks=ranks, backend="nccl"))     # collective: every rank gets here
         self.c_all_to_all = _lib.ALL_TO_ALL_FN(self._a2a)
         self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
+
+    def attach(self, lib, handle):
+        """vc_sp_init / vc_sp_init_rccl on one engine handle (called by the model when the engine is (re)configured)."""
+        if self.transport == "torch":
+            _lib.check(lib.vc_sp_init(handle, self.world_size, self.rank, self.c_all_to_all, self.c_all_gather, None), handle)
+            return
+        n = _lib.VC_RCCL_UNIQUE_ID_BYTES
+        ids = C.create_string_buffer(2 * n)
+        if self.rank == 0:
+            for i in range(2):
+                _lib.check(lib.vc_rccl_unique_id(C.byref(ids, i * n), n))
+        if self.world_size > 1:
+            box = [ids.raw if self.rank == 0 else None]
+            host_side = "gloo" in str(dist.get_backend_config(self.group))          # keep torch's own RCCL communicator unborn
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0), group=self.group,
+                                       device=torch.device("cpu") if host_side else None)
+            ids = C.create_string_buffer(box[0], 2 * n)
+        flags = _lib.VC_SP_FORCE_EXCHANGE if self.force_exchange else 0
+        _lib.check(lib.vc_sp_init_rccl(handle, self.world_size, self.rank, ids, 2, flags), handle)
+
+    def comm_ranks(self, lib, handle) -> int:
+        """World size the engine's RCCL communicator reports (ncclCommCount); 0 on the callback transport."""
+        return int(lib.vc_sp_comm_ranks(handle))
 
     def _buf(self, ptr, nbytes):
         key = (ptr, nbytes)
@@ -162,6 +215,12 @@ class SequenceParallel:
             t = alias_device_bytes(ptr, nbytes, torch.device("cuda", torch.cuda.current_device()))
             self._alias[key] = t
         return t
+
+    def _group_for(self, stream):
+        """The engine's two chains call back with two different streams (first seen: deterministic, the same program runs
+        on every rank); chain k uses process group k when there is more than one."""
+        lane = self._lane_of_stream.setdefault(stream, len(self._lane_of_stream))
+        return self._lane_groups[min(lane, len(self._lane_groups) - 1)]
 
     @staticmethod
     def _on(stream):
@@ -175,7 +234,7 @@ class SequenceParallel:
         try:
             n = bytes_per_peer * self.world_size
             with self._on(stream):
-                all_to_all_bytes(self._buf(send, n), self._buf(recv, n), self.group)
+                all_to_all_bytes(self._buf(send, n), self._buf(recv, n), self._group_for(stream))
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             self.error = e
@@ -184,7 +243,7 @@ class SequenceParallel:
     def _ag(self, ctx, send, recv, nbytes, stream):
         try:
             with self._on(stream):
-                all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self.group)
+                all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self._group_for(stream))
             return 0
         except Exception as e:
             self.error = e

@@ -338,7 +338,10 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             self._rope_dirty = False
         if self._sp_dirty:
             sp = self._sp
-            _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
+            if hasattr(sp, "attach"):
+                sp.attach(lib, h)            # RCCL communicators inside the engine, or the callback transport
+            else:                            # tests inject a bare callback object
+                _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
             self._sp_dirty = False
             changed = True
         if changed:
@@ -465,6 +468,10 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         _lib.check(_lib.load().vc_profile_read(self._engine_handle(), n, cnt, ms, fl, by), self._engine)
         return {k: dict(launches=int(cnt[i]), ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i]))
                 for i, k in enumerate(self.PROF_CLASSES)}
+
+    def sp_comm_ranks(self) -> int:
+        """Ranks of the engine-owned RCCL communicator (ncclCommCount); 0 when no RCCL exchange is configured."""
+        return 0 if self._engine is None else int(_lib.load().vc_sp_comm_ranks(self._engine))
 
     def workspace_bytes(self) -> int:
         return 0 if self._engine is None else int(_lib.load().vc_workspace_bytes(self._engine))
