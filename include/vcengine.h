@@ -51,6 +51,12 @@ typedef struct vc_config {
 #define VC_FWD_RUN_MAIN_BLOCKS 1u   /* run self.blocks (should_calc)                         */
 #define VC_FWD_STORE_RESIDUAL 2u    /* keep x_out - x_in  (previous_residual_cond)           */
 #define VC_FWD_USE_RESIDUAL 4u      /* x = x + previous_residual instead of the main blocks */
+#define VC_FWD_RESIDUAL_UNCOND 16u  /* with STORE / USE: the previous_residual_uncond slot (cond_flag=False, VC.py:391-394,
+                                       408-411) instead of previous_residual_cond.  A stored residual of B' samples serves a
+                                       later USE with B <= B' samples by its LAST B samples (previous_residual[-B:], VC.py:396:
+                                       what cfg_skip needs when it drops the unconditional half mid-sampling); the residuals
+                                       survive vc_prepare_video as long as the token geometry is unchanged.  The first STORE
+                                       of a slot allocates it (the only allocation vc_forward ever makes). */
 #define VC_FWD_SHARED_CFG_INPUT 8u  /* caller asserts: every sample has the SAME x, t and geoada_context (the CFG pair of
                                        PIPE.py:878-887 differs only in the prompt): block 0 of both chains computes its
                                        self-attention half once; results are bit-identical to the unflagged call */

@@ -89,6 +89,60 @@ def test_teacache_residual_path(model, fwd):
         model.disable_teacache()
 
 
+def _fresh_model():
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    m = VerseCrafterWanTransformer3DModel(**TINY)
+    m.load_state_dict(O.random_weights(O.Config(**TINY), 7))
+    return m.to(torch.bfloat16).to("cuda")
+
+
+def test_teacache_with_cfg_skip_crosses_the_batch_switch(fwd):
+    """TeaCache is on by default in the CLI and cfg_skip is a CLI knob (CLI.py:104, 122): when cfg_skip drops the
+    unconditional half mid-sampling the batch shrinks 2 -> 1, and a skipped step must re-add the LAST sample of the stored
+    residual (previous_residual[-x.size(0):], VC.py:396).  Expected value: the conditional half of the same sampler run
+    without cfg_skip (same gate decisions: the gate only sees the time embedding)."""
+    L = int(fwd["A.seq_len"])
+    xs = [fwd["A.x"], fwd["C.x2"], fwd["A.x"] * 0.5, fwd["C.x2"] * 0.75]
+    ts = [fwd["C.t1"], fwd["C.t2"], fwd["C.t2"] - 40.0, fwd["C.t2"] - 80.0]
+    a, b = _fresh_model(), _fresh_model()
+    for m in (a, b):                                    # step 0 computes, every later step is skipped (huge threshold)
+        m.enable_teacache([1.0, 0.0], num_steps=4, rel_l1_thresh=1e9, num_skip_start_steps=1, offload=False)
+    a.enable_cfg_skip(0.5, 4)                           # steps 2, 3: conditional half only
+    for i in range(4):
+        a.current_steps = b.current_steps = i
+        ya = run(a, fwd, L, x=xs[i], t=ts[i])
+        yb = run(b, fwd, L, x=xs[i], t=ts[i])
+        assert a.should_calc == b.should_calc == (i == 0)
+        if i < 2:
+            assert torch.equal(ya, yb)
+        else:
+            assert torch.equal(ya[0], ya[1]) and torch.equal(ya[1], yb[1]), i
+
+
+def test_teacache_keeps_separate_cond_and_uncond_residuals(fwd):
+    """cond_flag=False forwards (VC.py:391-394, 408-411) store and re-use previous_residual_uncond, never the conditional
+    residual; their gate decision is the conditional call's (WT.py:244-245)."""
+    L = int(fwd["A.seq_len"])
+    geo = fwd["A.geoada"].bfloat16().cuda()
+    ctx = [fwd["A.ctx0"].bfloat16().cuda(), fwd["A.ctx1"].bfloat16().cuda()]
+    xs = [fwd["A.x"].bfloat16().cuda(), fwd["C.x2"].bfloat16().cuda()]
+    ts = [fwd["C.t1"].cuda(), fwd["C.t2"].cuda()]
+    both, only_c, only_u = _fresh_model(), _fresh_model(), _fresh_model()
+    for m in (both, only_c, only_u):
+        m.enable_teacache([1.0, 0.0], num_steps=3, rel_l1_thresh=1e9, num_skip_start_steps=1, offload=False)
+    for i in range(2):
+        # the reference's un-batched CFG: a conditional forward, then an unconditional one with cond_flag=False
+        yc = both(xs[i][1:], ts[i][1:], geo[1:], ctx[1:], L, cond_flag=True)
+        yu = both(xs[i][:1], ts[i][:1], geo[:1], ctx[:1], L, cond_flag=False)
+        assert both.should_calc == (i == 0)
+        wc = only_c(xs[i][1:], ts[i][1:], geo[1:], ctx[1:], L)
+        wu = only_u(xs[i][:1], ts[i][:1], geo[:1], ctx[:1], L)
+        torch.cuda.synchronize()
+        assert torch.equal(yc, wc), i
+        assert torch.equal(yu, wu), i
+    assert not torch.equal(yc, yu)
+
+
 def test_enable_riflex_reaches_the_engine_and_is_reversible(fwd):
     """enable_riflex (WT.py:873-888, CLI.py:315-317) replaces one temporal frequency of the RoPE table (checked against the
     reference's table in test_oracle_golden.py).  On a 3-frame clip its effect on the output (2e-3 relative) is below the
@@ -364,3 +418,48 @@ def test_fused_sampler_update_equals_torch_formulation_bitwise(n_steps, shift, d
         assert xb.dtype == torch.bfloat16 and torch.equal(xa, xb), f"step {i}: max diff {(xa.float() - xb.float()).abs().max()}"
         assert torch.equal(a.model_outputs[-1], b.model_outputs[-1]) and torch.equal(a.last_sample, b.last_sample)
     assert torch.isfinite(xb.float()).all()
+
+
+@pytest.mark.parametrize("n_steps,shift,do_cfg", [(8, 16.0, True), (5, 5.0, True), (6, 16.0, False), (2, 16.0, True), (50, 16.0, True)])
+def test_fused_sampler_update_vs_unipc_oracle_per_step(n_steps, shift, do_cfg):
+    """FlowUniPCMultistepScheduler.step_cfg (ONE HIP kernel: CFG combine, x0, UniPC corrector, predictor) against
+    oracle/unipc_oracle.py (float64, closed forms; third-party algorithm: parity unpinned) -- every step type of a run: first
+    step, order-1 and order-2 corrector / predictor, lower-order final step.
+
+    Per step the oracle is loaded with the kernel's own bf16 state (sample, last sample, the two previous x0) so that one
+    update is compared, not accumulated drift.  Tolerance: the kernel rounds to bf16 after each of the <= 14 elementwise ops of
+    the torch formulation it reproduces; with |coefficients| <= ~2 the worst case is a handful of half-ulps of the largest
+    term: |hip - oracle| <= 8 * 2^-8 * max(|sample|, |x0|, |noise|) elementwise-max norm.  Measured: <= 2.5 of those ulps.
+    The free-running trajectories (no re-synchronisation) must stay within 3e-2 relative L2 after the whole run."""
+    import numpy as np
+    from oracle.unipc_oracle import UniPCOracle, cfg_combine
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    g = torch.Generator().manual_seed(n_steps * 100 + int(shift))
+    shape = (1, 16, 3, 8, 12)
+    xb = torch.randn(shape, generator=g).bfloat16().cuda()
+    b = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    b.set_timesteps(n_steps, device="cuda", shift=shift)
+    orc, free = UniPCOracle(n_steps, shift), UniPCOracle(n_steps, shift)
+    assert np.array_equal(orc.timesteps, b.timesteps.cpu().numpy())
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    x_free = f64(xb)
+    guidance, worst = 5.0, 0.0
+    for i, t in enumerate(b.timesteps):
+        npred = torch.randn((2 if do_cfg else 1,) + shape[1:], generator=g).bfloat16().cuda()
+        v = cfg_combine(f64(npred[:1]), f64(npred[1:]), guidance) if do_cfg else f64(npred)
+        # oracle state := the kernel's state before this step
+        orc.i = i
+        orc.m = [f64(m) for m in b.model_outputs if m is not None][-2:]
+        orc.last_sample = None if b.last_sample is None else f64(b.last_sample)
+        orc.order_used, orc.lower = b.this_order if i > 0 else 1, b.lower_order_nums
+        want = orc.step(v, f64(xb))
+        x_free = free.step(v, x_free)
+        scale = max(float(xb.float().abs().max()), float(np.abs(v).max()), float(np.abs(orc.m[-1]).max()))
+        xb = b.step_cfg(npred, t, xb, guidance if do_cfg else None)
+        torch.cuda.synchronize()
+        err = float(np.abs(f64(xb) - want).max()) / (2.0 ** -8 * scale)
+        worst = max(worst, err)
+        assert err <= 8.0, f"step {i}: {err:.2f} bf16 ulps of {scale:.3g}"
+    rel_free = float(np.linalg.norm(f64(xb) - x_free) / np.linalg.norm(x_free))
+    print(f"unipc n={n_steps} shift={shift}: worst per-step error {worst:.2f} ulp_bf16, free-running rel L2 {rel_free:.3g}")
+    assert rel_free < 3e-2

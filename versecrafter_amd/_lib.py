@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("VC_ENGINE_LIB", os.path.join(_HERE, "libvcengine.so")
 VC_OK = 0
 VC_E_INVALID, VC_E_HIP, VC_E_STATE, VC_E_NOMEM, VC_E_UNSUPPORTED = -1, -2, -3, -4, -5
 VC_FWD_RUN_MAIN_BLOCKS, VC_FWD_STORE_RESIDUAL, VC_FWD_USE_RESIDUAL, VC_FWD_SHARED_CFG_INPUT = 1, 2, 4, 8
+VC_FWD_RESIDUAL_UNCOND = 16
 VC_MAX_GEOADA_LAYERS = 64
 VC_ABI_VERSION = 2
 VC_RCCL_UNIQUE_ID_BYTES = 128

@@ -81,12 +81,17 @@ struct vc_engine {
     // prepared video
     bool prepared = false;
     int B = 0, T = 0, H = 0, W = 0, H2 = 0, W2 = 0, L = 0, Lpad = 0, Lloc = 0, M = 0, tok_off = 0;
-    bool have_residual = false;
+    // TeaCache residuals (VC.py:390-411): previous_residual_cond / _uncond, [resid_B][resid_L][dim] bf16.  They live outside the
+    // per-video arena so that they survive a change of batch size between steps (cfg_skip halves the batch mid-sampling and
+    // the reference then reads previous_residual[-B:], VC.py:396); allocated at the first STORE_RESIDUAL of a slot.
+    void* resid[2] = {nullptr, nullptr};
+    int64_t resid_cap[2] = {0, 0};
+    int resid_B[2] = {0, 0}, resid_L[2] = {0, 0};
 
     // workspace
     char* arena = nullptr;
     int64_t arena_bytes = 0;
-    void *x, *c, *c0, *x0, *resid, *patchA, *ctxpad, *ctxh, *ctx, *headmod, *ybuf, *yfull;
+    void *x, *c, *c0, *patchA, *ctxpad, *ctxh, *ctx, *headmod, *ybuf, *yfull;
     void* hint[2];                  // hint ring (2 slots when the chains run concurrently)
     Lane lane[2];
     bool dual = false;              // adapter chain on its own stream (sequence-parallel runs: hides the exchanges)
@@ -504,6 +509,7 @@ void vc_destroy(vc_engine* h) {
     for (auto e : h->ev_hint) if (e) (void)hipEventDestroy(e);
     for (auto e : h->ev_used) if (e) (void)hipEventDestroy(e);
     free_arena(h);
+    for (int k = 0; k < 2; ++k) if (h->resid[k]) (void)hipFree(h->resid[k]);
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     if (h->rope_dev) (void)hipFree(h->rope_dev);
     if (h->small) (void)hipFree(h->small);
@@ -631,7 +637,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         h->dual = dl ? atoi(dl) == 1 : h->sp_exchange;
     }
     const int nlanes = h->dual ? 2 : 1;
-    const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md), o_x0 = take(md), o_resid = take(md);
+    const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md);
     int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2];
     for (int l = 0; l < 2; ++l) {
         if (l < nlanes) {
@@ -668,7 +674,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     }
     h->arena_bytes = off;
     char* a = h->arena;
-    h->x = a + o_x; h->c = a + o_c; h->c0 = a + o_c0; h->x0 = a + o_x0; h->resid = a + o_resid; h->patchA = a + o_patch;
+    h->x = a + o_x; h->c = a + o_c; h->c0 = a + o_c0; h->patchA = a + o_patch;
     h->ctxpad = a + o_ctxpad; h->ctxh = a + o_ctxh; h->ctx = a + o_ctx; h->headmod = a + o_headmod;
     h->ybuf = a + o_y; h->yfull = a + o_yfull;
     for (int l = 0; l < 2; ++l) {
@@ -686,7 +692,9 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     }
     for (int i = 0; i < 8; ++i) h->text_lens[i] = i < B ? text_lens[i] : 0;
     h->B = B; h->T = T; h->H = H; h->W = Wd; h->H2 = H / 2; h->W2 = Wd / 2; h->L = L; h->Lpad = Lpad; h->Lloc = Lloc;
-    h->M = M; h->tok_off = h->rank * Lloc; h->have_residual = false;
+    h->M = M; h->tok_off = h->rank * Lloc;
+    for (int k = 0; k < 2; ++k)
+        if (h->resid_L[k] != Lloc) h->resid_B[k] = 0;        // another token geometry: the stored residual is meaningless
 
     // ---- control-map patch embedding (VC.py:262-270): c0 = Conv3d(geoada_context), zero-padded rows ----
     VCCHK(h, vc_launch_patchify(geoada_context, h->patchA, B, c.geoada_in_dim, T, H, Wd, Lloc, h->tok_off, s));
@@ -738,7 +746,10 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                use_res = flags & VC_FWD_USE_RESIDUAL;
     const bool shared0 = (flags & VC_FWD_SHARED_CFG_INPUT) && h->B >= 2;   // see run_block(shared_sa)
     if (run_main == use_res) return fail(h, VC_E_INVALID, "vc_forward: exactly one of RUN_MAIN_BLOCKS / USE_RESIDUAL");
-    if (use_res && !h->have_residual) return fail(h, VC_E_STATE, "vc_forward: no stored residual to re-use");
+    const int slot = (flags & VC_FWD_RESIDUAL_UNCOND) ? 1 : 0;
+    if (use_res && (h->resid_B[slot] < h->B || h->resid_L[slot] != h->Lloc))
+        return fail(h, VC_E_STATE, "vc_forward: no stored %s residual for %d sample(s) to re-use (stored: %d)",
+                    slot ? "uncond" : "cond", h->B, h->resid_L[slot] == h->Lloc ? h->resid_B[slot] : 0);
     hipStream_t s = (hipStream_t)stream;
     const vc_config& c = h->cfg;
     const int d = c.dim, M = h->M, B = h->B, Lloc = h->Lloc;
@@ -758,7 +769,19 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     Lane& L0 = h->lane[0];
     L0.idx = 0; L0.s = s;
     if (run_main) {
-        if (store_res) HIPCHK(h, hipMemcpyAsync(h->x0, h->x, md, hipMemcpyDeviceToDevice, s));
+        if (store_res) {                                     // ori_x = x.clone()  (VC.py:398)
+            if (h->resid_cap[slot] < md) {                   // first use of the slot (or a larger batch): one-time allocation
+                if (h->resid[slot]) HIPCHK(h, hipFree(h->resid[slot]));
+                h->resid[slot] = nullptr; h->resid_cap[slot] = 0; h->resid_B[slot] = 0;
+                if (hipMalloc(&h->resid[slot], md) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(h, VC_E_NOMEM, "hipMalloc of the %lld-byte TeaCache residual failed", (long long)md);
+                }
+                h->resid_cap[slot] = md;
+            }
+            h->resid_B[slot] = 0;
+            HIPCHK(h, hipMemcpyAsync(h->resid[slot], h->x, md, hipMemcpyDeviceToDevice, s));
+        }
         const int NA = (int)h->gblocks.size();
         // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
         auto adapter_block = [&](int n, Lane& la, int nslots) -> int {
@@ -830,11 +853,13 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             }
         }
         if (store_res) {                                     // previous_residual_cond = x - ori_x (VC.py:409)
-            VCCHK(h, vc_launch_sub(h->x, h->x0, h->resid, (int64_t)M * d, s));
-            h->have_residual = true;
+            VCCHK(h, vc_launch_sub(h->x, h->resid[slot], h->resid[slot], (int64_t)M * d, s));
+            h->resid_B[slot] = B; h->resid_L[slot] = Lloc;
         }
     } else {
-        VCCHK(h, vc_launch_axpy(h->x, h->resid, h->x, 1.0f, (int64_t)M * d, s));   // VC.py:396
+        // x = x + previous_residual[-B:]  (VC.py:390-396: the last B samples of what was stored)
+        const char* pr = (const char*)h->resid[slot] + (int64_t)(h->resid_B[slot] - B) * Lloc * d * 2;
+        VCCHK(h, vc_launch_axpy(h->x, pr, h->x, 1.0f, (int64_t)M * d, s));
     }
 
     // ---- head (WT.py:631-644) ----

@@ -426,10 +426,14 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             if cond_flag:
                 e0 = self.time_embedding_e0(tf).to(torch.bfloat16)               # e0.to(dtype), VC.py:353
                 self.should_calc = self.teacache.gate(e0)
+            else:
+                self.should_calc = self.teacache.should_calc                       # WT.py:244-245
             if self.should_calc:
                 flags = _lib.VC_FWD_RUN_MAIN_BLOCKS | _lib.VC_FWD_STORE_RESIDUAL
             else:
                 flags = _lib.VC_FWD_USE_RESIDUAL
+            if not cond_flag:                                                      # previous_residual_uncond, VC.py:391-394
+                flags |= _lib.VC_FWD_RESIDUAL_UNCOND
         xc = x.contiguous()
         # CFG pair of the reference's sampler (PIPE.py:878-887: latents, timestep and control maps duplicated, prompts differ):
         # the engine then computes the prompt-independent prefix of block 0 of both chains once (bit-identical result).

@@ -25,18 +25,23 @@ class WanPipelineOutput:
 
 
 def geoada_encode_masks(masks, vae_stride=(4, 8, 8)) -> List[torch.Tensor]:
-    """PIPE.py:440-486 (ref_images=None): per sample [C,T,H,W] mask -> [64, (T+3)//4, H/8, W/8] by an 8x8
-    pixel-unshuffle of channel 0 and a nearest-exact resize of the frame axis."""
-    out = []
+    """Mask planes of the GeoAdapter context (what PIPE.py:440-486 produces for ref_images=None): channel 0 of each
+    per-sample [C,F,H,W] mask becomes [64, (F+3)//4, H/8, W/8] -- plane 8*i+j holds pixel (8y+i, 8x+j) of latent cell
+    (y, x), and latent frame n shows source frame floor((n + 0.5) * F / T) (nearest-exact).  Host path for CPU tensors and
+    pre-computed inputs; on the GPU the pipeline uses the HIP kernel (ops.geoada_context).  Pinned bit-exact against the
+    reference's own function by tests/golden/pipe_trace.safetensors."""
+    st, sh, sw = vae_stride
+    assert sh == sw, "square spatial stride (the reference reshapes both axes by vae_stride[1])"
+    planes = []
     for mask in masks:
-        c, depth, height, width = mask.shape
-        new_depth = int((depth + 3) // vae_stride[0])
-        height = 2 * (int(height) // (vae_stride[1] * 2))
-        width = 2 * (int(width) // (vae_stride[2] * 2))
-        m = mask[0].view(depth, height, vae_stride[1], width, vae_stride[1])
-        m = m.permute(2, 4, 0, 1, 3).reshape(vae_stride[1] * vae_stride[2], depth, height, width)
-        out.append(F.interpolate(m.unsqueeze(0), size=(new_depth, height, width), mode="nearest-exact").squeeze(0))
-    return out
+        frames, rows, cols = mask.shape[1], 2 * (mask.shape[2] // (2 * sh)), 2 * (mask.shape[3] // (2 * sw))
+        if mask.shape[2] != rows * sh or mask.shape[3] != cols * sw:
+            raise RuntimeError(f"mask {tuple(mask.shape)} does not tile into {sh}x{sw} cells on an even latent grid")
+        t_out = (frames + 3) // st
+        src = torch.clamp(((torch.arange(t_out, dtype=torch.float64) + 0.5) * (frames / t_out)).floor().long(), max=frames - 1)
+        cells = F.pixel_unshuffle(mask[0].index_select(0, src.to(mask.device)).unsqueeze(1), sh)   # [T, 64, rows, cols]
+        planes.append(cells.transpose(0, 1).contiguous())
+    return planes
 
 
 def geoada_latent(z, m):
