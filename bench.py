@@ -239,6 +239,7 @@ def run_rank(args):
     scheduler.set_timesteps(args.num_inference_steps, device=dev, shift=16)
     ts = scheduler.timesteps
     seq_len = L
+    pipe._cfg_pair_maps = geoada_in            # as __call__ does: the control maps of the CFG pair are one tensor stacked twice
 
     def run_steps(lat, first, n):
         for i in range(first, first + n):

@@ -96,6 +96,35 @@ def test_from_pretrained_rules(tmp_path):
         VerseCrafterWanTransformer3DModel.from_pretrained(str(tmp_path / "nope"))
 
 
+def test_from_pretrained_bin_shards_and_missing_keys(tmp_path):
+    """WT.py:1220, 1281: a pickle checkpoint (read with torch.load(weights_only=True): nothing executed) and the sharded
+    *.safetensors glob load the same tensors; keys the checkpoint lacks are initialised (never left as raw memory)."""
+    cfg = O.Config(**TINY)
+    W = O.random_weights(cfg, 5)
+    json.dump(dict(TINY), open(tmp_path / "config.json", "w"))
+    drop = {"blocks.3.ffn.2.bias", "geoada_blocks.1.after_proj.weight", "head.head.weight"}
+    torch.save({k: v for k, v in W.items() if k not in drop}, str(tmp_path / "diffusion_pytorch_model.bin"))
+    a = VerseCrafterWanTransformer3DModel.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16)
+    sa = a.state_dict()
+    for k, v in W.items():
+        if k not in drop:
+            assert torch.equal(sa[k], v.bfloat16()), k
+    assert sa["blocks.3.ffn.2.bias"].abs().max() == 0                       # bias family: zeros
+    assert sa["head.head.weight"].abs().max() == 0                          # zero-initialised output (WT.py:1174)
+    assert sa["geoada_blocks.1.after_proj.weight"].abs().max() == 0         # VC.py:106-110
+    assert all(torch.isfinite(v.float()).all() for v in sa.values())
+
+    shards = tmp_path / "sharded"
+    shards.mkdir()
+    json.dump(dict(TINY), open(shards / "config.json", "w"))
+    keys = sorted(W)
+    save_file({k: W[k] for k in keys[::2]}, str(shards / "model-00001-of-00002.safetensors"))
+    save_file({k: W[k] for k in keys[1::2]}, str(shards / "model-00002-of-00002.safetensors"))
+    b = VerseCrafterWanTransformer3DModel.from_pretrained(str(shards), torch_dtype=torch.bfloat16)
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, W[k].bfloat16()), k
+
+
 def test_geoada_encode_masks_matches_oracle():
     g = torch.Generator().manual_seed(0)
     mask = (torch.rand(3, 9, 64, 96, generator=g) < 0.5).float()

@@ -358,13 +358,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
 template <bool SEG, int NW, bool MERGE = false>
 int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
     constexpr int QB = NW * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<SEG, NW, MERGE>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return VC_E_HIP;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!vc_set_lds_once(attr_done, (const void*)attn_fwd_pipe_kernel<SEG, NW, MERGE>, LDS_BYTES)) return VC_E_HIP;
     const int nQ = (p.Lq + QB - 1) / QB;
     const int nwork = p.B * p.H * nQ;
     const int grid = (nwork + 7) / 8 * 8;

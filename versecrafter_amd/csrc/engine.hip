@@ -26,8 +26,6 @@
 #include "../../include/vcengine.h"
 #include "vc_kernels.h"
 
-extern int vc_gemm_tile_override;
-
 namespace {
 
 struct WeightSlot {
@@ -72,6 +70,7 @@ struct vc_engine {
 
     // sequence parallel
     int P = 1, rank = 0;
+    bool pad_merge = true;          // fold the zero-padded prompt keys of cross-attention (VC_NO_PAD_MERGE=1 at vc_create: off)
     bool sp_exchange = false;       // self-attention goes through the Ulysses exchange (P > 1; or forced at P = 1 for tests)
     VcComm* comm[2] = {nullptr, nullptr};   // RCCL transport: one communicator per block chain (lane), vc_sp_init_rccl
     vc_all_to_all_fn a2a = nullptr; // callback transport (vc_sp_init): tests / hosts that bring their own collective
@@ -382,7 +381,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
         a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
-        if (B <= 8 && !getenv("VC_NO_PAD_MERGE")) {             // the zero-padded prompt positions are identical K / V rows
+        if (B <= 8 && h->pad_merge) {             // the zero-padded prompt positions are identical K / V rows
             a.pad_merge = 1;
             for (int i = 0; i < B; ++i) a.pad_from[i] = h->text_lens[i];
         }
@@ -438,6 +437,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
         return fail(nullptr, VC_E_HIP, "vc_create: no HIP device (this library has no CPU path)");
     vc_engine* h = new vc_engine();
     h->cfg = *cfg;
+    h->pad_merge = getenv("VC_NO_PAD_MERGE") == nullptr;
     if (cfg->num_geoada_layers > 0) {
         if (cfg->num_geoada_layers > VC_MAX_GEOADA_LAYERS) { delete h; return fail(nullptr, VC_E_INVALID, "too many geoada layers"); }
         h->geoada_layers.assign(cfg->geoada_layers, cfg->geoada_layers + cfg->num_geoada_layers);
@@ -911,11 +911,8 @@ int vc_op_gemm_bf16(const void* A, int64_t lda, const void* Wt, int64_t ldw, voi
     p.epilogue = epilogue; p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_bstride = gate_bstride;
     p.rows_per_batch = rows_per_batch; p.hint = hint; p.ldh = ldh; p.hint_scale = hint_scale; p.valid_rows = -1;
     p.a_rows_padded = tile == 4;     // tile 4 (tests / tuning): the caller promises A is readable up to the next 256 rows
-    const int prev = vc_gemm_tile_override;
-    vc_gemm_tile_override = tile;
-    const int r = vc_launch_gemm(p, (hipStream_t)stream);
-    vc_gemm_tile_override = prev;
-    return r;
+    p.tile = tile;
+    return vc_launch_gemm(p, (hipStream_t)stream);
 }
 
 int vc_op_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,

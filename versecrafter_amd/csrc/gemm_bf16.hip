@@ -495,12 +495,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 
 int launch_pp(const VcGemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 65536;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return VC_E_HIP;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel, LDS)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
     const int ntiles = nTm * nTn;
@@ -511,13 +507,8 @@ int launch_pp(const VcGemmParams& p, hipStream_t stream) {
 
 template <class Cfg, bool SB = false>
 int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<Cfg, SB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return VC_E_HIP;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_bf16_kernel<Cfg, SB>, Cfg::LDS_BYTES)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + Cfg::BM - 1) / Cfg::BM, nTn = ng * ((p.N + Cfg::BN - 1) / Cfg::BN);
     const int ntiles = nTm * nTn;
@@ -529,8 +520,6 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int vc_gemm_tile_override = 0;   // 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel (tests)
-
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
     if (p.K % 64 != 0 || p.N % 4 != 0) return VC_E_UNSUPPORTED;
@@ -541,17 +530,18 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (p.ngroups < 0 || p.ngroups > 3) return VC_E_INVALID;
     for (int g = 1; g < p.ngroups; ++g)
         if (!p.Wg[g - 1] || !p.Cg[g - 1]) return VC_E_INVALID;
+    // p.tile (tests / tuning): 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel
     bool big = (p.M >= 1024 && p.N >= 256);
-    if (vc_gemm_tile_override == 1) big = false;
-    if (vc_gemm_tile_override == 2) big = true;
+    if (p.tile == 1) big = false;
+    if (p.tile == 2) big = true;
     // every tile row readable (M a multiple of 256 or padded buffers), N % 256 == 0, K % 128 == 0: ping-pong kernel
     const bool rows_ok = (p.M % 256 == 0) || p.a_rows_padded;
     if (big && rows_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
-        (vc_gemm_tile_override == 0 || vc_gemm_tile_override == 4))
+        (p.tile == 0 || p.tile == 4))
         return launch_pp(p, stream);
     // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
-    if (big && fits32 && vc_gemm_tile_override != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);
+    if (big && fits32 && p.tile != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);
     if (big) return launch_cfg<GemmCfg<256, 256, 2, 4>>(p, stream);
     return launch_cfg<GemmCfg<128, 128, 2, 2>>(p, stream);
 }

@@ -13,6 +13,19 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define VC_DEVICE __device__ __forceinline__
 
+// Host: hipFuncSetAttribute(max dynamic LDS) once per (kernel, device).  `done` is a function-local static of the launcher: one
+// bit per device ordinal (a process that drives several GPUs sets the attribute on each of them).
+#include <atomic>
+inline bool vc_set_lds_once(std::atomic<uint64_t>& done, const void* kernel, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
 // ---- bf16 <-> f32 -------------------------------------------------------------------------
 VC_DEVICE float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 VC_DEVICE float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }

@@ -37,6 +37,7 @@ struct VcGemmParams {
     int rows_per_batch;              // rows per sample (for gate and valid_rows); 0 -> M
     int a_rows_padded;               // rows of A up to the next multiple of 256 are readable (engine workspace)
     int valid_rows;                  // >= 0: rows with (m % rows_per_batch) >= valid_rows are written as 0; < 0: off
+    int tile;                        // kernel selection for tests / tuning (0 = auto; see vc_launch_gemm)
 };
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream);
 

@@ -56,6 +56,7 @@ class WanVerseCrafterPipeline:
         self._guidance_scale = 1.0
         self._interrupt = False
         self._device = None
+        self._cfg_pair_maps = None      # the [maps, maps] stack __call__ built for classifier-free guidance
 
     # -- small parts of the DiffusionPipeline surface the CLI touches ---------------------------------
     def to(self, device):
@@ -139,6 +140,9 @@ class WanVerseCrafterPipeline:
         if hasattr(self.scheduler, "scale_model_input"):
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
         timestep = t.expand(latent_model_input.shape[0])
+        if do_cfg and latents.shape[0] == 1 and self._cfg_pair_maps is geoada_context_input and \
+                hasattr(self.transformer, "assert_cfg_pair"):
+            self.transformer.assert_cfg_pair(latent_model_input)    # [u, u] built right here and in __call__: no device check
         noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
                                       geoada_context=geoada_context_input, seq_len=seq_len,
                                       geoada_context_scale=geoada_context_scale)
@@ -213,6 +217,7 @@ class WanVerseCrafterPipeline:
         self.transformer.num_inference_steps = num_inference_steps                  # PIPE.py:869
         # the reference re-stacks this every step (PIPE.py:883-887); it is step-invariant
         geoada_context_input = torch.stack(geoada_context * 2) if do_cfg else torch.stack(geoada_context)
+        self._cfg_pair_maps = geoada_context_input if (do_cfg and len(geoada_context) == 1) else None
 
         for i, t in enumerate(timesteps):                                           # PIPE.py:871
             if self.interrupt:
