@@ -104,6 +104,11 @@ int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, i
 int vc_sp_comm_ranks(const vc_engine* h);
 int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
 int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream);
+/* What-if timing of ONE rank of a `world`-way run on a single GPU (tools/sim_sp_rank.py): every exchange is a local copy
+ * followed by one idle wave that holds the chain's stream for (bytes leaving the rank) / egress_gbps -- the rank's compute
+ * share, the pack / unpack passes, the two-chain schedule and the exposure of the wire time are real, the RESULTS ARE NOT
+ * (no peer data).  Never used by the product path. */
+int vc_sp_init_sim(vc_engine* h, int world, int rank, double egress_gbps);
 
 /* Step-invariant part of forward, hoisted (once per video): geoada_patch_embedding (VC.py:262-267),
  * text_embedding (VC.py:358-363) and every block's cross-attention k/v (WT.py:421-422).

@@ -73,6 +73,7 @@ struct vc_engine {
     bool pad_merge = true;          // fold the zero-padded prompt keys of cross-attention (VC_NO_PAD_MERGE=1 at vc_create: off)
     bool sp_exchange = false;       // self-attention goes through the Ulysses exchange (P > 1; or forced at P = 1 for tests)
     VcComm* comm[2] = {nullptr, nullptr};   // RCCL transport: one communicator per block chain (lane), vc_sp_init_rccl
+    double sim_gbps = 0;            // > 0: what-if transport (vc_sp_init_sim): local copy + a delay of egress bytes / sim_gbps
     vc_all_to_all_fn a2a = nullptr; // callback transport (vc_sp_init): tests / hosts that bring their own collective
     vc_all_gather_fn ag = nullptr;
     void* cb_ctx = nullptr;
@@ -265,6 +266,11 @@ int sp_all_to_all(vc_engine* h, const Lane& ln, const void* send, void* recv, in
             return fail(h, VC_E_HIP, "all_to_all (%s): %s", what, vc_comm_error());
         return VC_OK;
     }
+    if (h->sim_gbps > 0) {            // timing model only: the data stay local, the stream is held for the wire time
+        HIPCHK(h, hipMemcpyAsync(recv, send, (size_t)bytes_per_peer * h->P, hipMemcpyDeviceToDevice, ln.s));
+        VCCHK(h, vc_launch_delay((double)bytes_per_peer * (h->P - 1) / (h->sim_gbps * 1e3), ln.s));
+        return VC_OK;
+    }
     if (!h->a2a || h->a2a(h->cb_ctx, send, recv, bytes_per_peer, (void*)ln.s) != 0)
         return fail(h, VC_E_STATE, "all_to_all callback failed (%s)", what);
     return VC_OK;
@@ -273,6 +279,12 @@ int sp_all_gather(vc_engine* h, const Lane& ln, const void* send, void* recv, in
     if (h->comm[ln.idx]) {
         if (vc_comm_all_gather(h->comm[ln.idx], send, recv, bytes, ln.s) != VC_OK)
             return fail(h, VC_E_HIP, "all_gather: %s", vc_comm_error());
+        return VC_OK;
+    }
+    if (h->sim_gbps > 0) {
+        for (int r = 0; r < h->P; ++r)
+            HIPCHK(h, hipMemcpyAsync((char*)recv + (int64_t)r * bytes, send, (size_t)bytes, hipMemcpyDeviceToDevice, ln.s));
+        VCCHK(h, vc_launch_delay((double)bytes * (h->P - 1) / (h->sim_gbps * 1e3), ln.s));
         return VC_OK;
     }
     if (!h->ag || h->ag(h->cb_ctx, send, recv, bytes, (void*)ln.s) != 0) return fail(h, VC_E_STATE, "all_gather callback failed");
@@ -556,7 +568,7 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
     if (h->cfg.num_heads % world)
         return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
-    h->P = world; h->rank = rank; h->a2a = a2a; h->ag = ag; h->cb_ctx = ctx;
+    h->P = world; h->rank = rank; h->a2a = a2a; h->ag = ag; h->cb_ctx = ctx; h->sim_gbps = 0;
     h->sp_exchange = world > 1;
     h->prepared = false;
     return VC_OK;
@@ -584,8 +596,20 @@ int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, i
             return fail(h, r, "vc_sp_init_rccl (chain %d): %s", l, vc_comm_error());
         }
     }
-    h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr;
+    h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr; h->sim_gbps = 0;
     h->sp_exchange = world > 1 || (flags & VC_SP_FORCE_EXCHANGE);
+    h->prepared = false;
+    return VC_OK;
+}
+
+int vc_sp_init_sim(vc_engine* h, int world, int rank, double egress_gbps) {
+    if (!h) return VC_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || !(egress_gbps > 0)) return fail(h, VC_E_INVALID, "vc_sp_init_sim: bad argument");
+    if (h->cfg.num_heads % world)
+        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
+    for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
+    h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr; h->sim_gbps = egress_gbps;
+    h->sp_exchange = true;
     h->prepared = false;
     return VC_OK;
 }

@@ -315,6 +315,30 @@ int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64
     return ok();
 }
 
+// Occupies `st` for `usec` microseconds with one idle wave (what-if timing of an exchange's wire time: tools/sim_sp_rank.py).
+// The wave polls the constant-rate wall clock and sleeps in between; it exits on the deadline or after a fixed number of polls.
+__global__ void delay_kernel(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    for (int i = 0; i < (1 << 24); ++i) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+int vc_launch_delay(double usec, hipStream_t st) {
+    if (!(usec >= 0) || usec > 5e6) return VC_E_INVALID;
+    static int khz = 0;
+    if (!khz) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { khz = 0; return VC_E_HIP; }
+    }
+    const uint64_t ticks = (uint64_t)(usec * 1e-3 * khz);
+    if (ticks == 0) return VC_OK;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, ticks);
+    return ok();
+}
+
 int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st) {
     if (!qkv || !send || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
     hipLaunchKernelGGL(sp_pack_qkv_kernel, dim3(grid_for((int64_t)M * 3 * d / 8, 256)), dim3(256), 0, st,

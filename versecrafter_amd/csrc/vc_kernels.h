@@ -104,6 +104,8 @@ int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, v
 //   unpack recv [P_src][M][d/P] -> attn [M, d]
 int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st);
 int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st);
+// one idle wave holds the stream for `usec` microseconds (what-if timing only)
+int vc_launch_delay(double usec, hipStream_t st);
 // generic strided 2-D copy
 int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
                            hipStream_t st);
