@@ -323,7 +323,8 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         `sp_group`: a torch.distributed group (default: the one set_multi_gpus_devices made), or an object with
         the SequenceParallel interface (world_size, rank, c_all_to_all, c_all_gather) -- tests inject one."""
         from .. import dist as vdist
-        self._sp = sp_group if hasattr(sp_group, "c_all_to_all") else vdist.SequenceParallel(sp_group)
+        custom = hasattr(sp_group, "c_all_to_all") or hasattr(sp_group, "attach")
+        self._sp = sp_group if custom else vdist.SequenceParallel(sp_group)
         self.sp_world_size = self._sp.world_size
         self.sp_world_rank = self._sp.rank
         self.all_gather = getattr(self._sp, "all_gather_dim1", None)
