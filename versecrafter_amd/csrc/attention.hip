@@ -35,6 +35,12 @@ namespace {
 #ifndef VC_ATTN_DEFER_MAX
 #define VC_ATTN_DEFER_MAX 8
 #endif
+#ifndef VC_ATTN_ROWSUM
+#define VC_ATTN_ROWSUM 4
+#endif
+#ifndef VC_ATTN_ABLATE
+#define VC_ATTN_ABLATE 0
+#endif
 
 constexpr int D = 128;
 constexpr int KT = 64;      // keys per tile
@@ -291,17 +297,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         const float mc = m_run * c;
         // ---- phase 1: MFMA S(t+1) = K(t+1).Q^T  ||  VALU P(t) = exp2(S(t) c - m c), row sums, bf16 pack ----
         if (MORE) qk(smem + P_KST + (PAR ^ 1) * TILE_BYTES, Sn);
-        float ps = 0.f;
+        // row sums: VC_ATTN_ROWSUM independent partial sums, reduced and pinned HERE -- left to itself hipcc sinks the whole
+        // 32-add dependency chain behind the next barrier, where no MFMA of this wave can cover it (0: the unpinned chain)
+        constexpr int NPS = VC_ATTN_ROWSUM > 0 ? VC_ATTN_ROWSUM : 1;
+        float ps[NPS];
+#pragma unroll
+        for (int i = 0; i < NPS; ++i) ps[i] = 0.f;
         bf16x8 pf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+#if VC_ATTN_ABLATE == 1        // timing ablation only (wrong results): the transcendental replaced by a plain VALU op
+                const float pe = Sc[s >> 1][8 * (s & 1) + j] * c - mc;
+#else
                 const float pe = __builtin_amdgcn_exp2f(Sc[s >> 1][8 * (s & 1) + j] * c - mc);
-                ps += pe;
+#endif
+                ps[(s * 8 + j) % NPS] += pe;
                 pf[s][j] = (__bf16)pe;
             }
-        l_run += ps;
+        {
+            float tot = ps[0];
+#pragma unroll
+            for (int i = 1; i < NPS; ++i) tot += ps[i];
+            l_run += tot;
+        }
+        if (VC_ATTN_ROWSUM > 0) asm volatile("" : "+v"(l_run));
         // ---- phase 2: MFMA O += V(t)^T.P(t)^T  ||  VALU row maxima of S(t+1) ----
         const char* vbuf = smem + P_VST + PAR * TILE_BYTES;
 #pragma unroll
