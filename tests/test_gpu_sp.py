@@ -102,11 +102,17 @@ def make_model(weights):
     return m.to(torch.bfloat16).to("cuda")
 
 
-@pytest.mark.parametrize("P,seq_len,cfg_pair", [(2, 72, False), (4, 72, False), (2, 75, False), (2, 72, True), (4, 75, True)])
-def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair):
+@pytest.mark.parametrize("P,seq_len,cfg_pair,lanes", [
+    (2, 72, False, None), (4, 72, False, None), (2, 75, False, None), (2, 72, True, None), (4, 75, True, None),
+    (2, 75, True, "0"), (2, 75, True, "1"), (2, 75, False, "1"), (4, 72, True, "2")])
+def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch):
     """seq_len 75 -> padded to 76 for P=2 (WT.py:195-196): compared against SP(1) run at seq_len 76.
     cfg_pair: both samples carry the same latent / control maps (the sampler's CFG pair): the shared block-0 prefix of the
-    engine is active on every rank and in the single-rank reference."""
+    engine is active on every rank and in the single-rank reference.
+    lanes: the engine's stream schedule (VC_DUAL_LANE): None = default (B = 2 under sequence parallelism: sample lanes -- one
+    sample per stream and communicator), "0" one stream, "1" chain lanes (GeoAdapter chain on its own stream), "2" sample lanes."""
+    if lanes is not None:
+        monkeypatch.setenv("VC_DUAL_LANE", lanes)
     cfg = O.Config(**TINY)
     W = O.random_weights(cfg, 11)
     g = torch.Generator().manual_seed(1)
@@ -148,7 +154,9 @@ def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair):
     torch.cuda.synchronize()
     for r in range(P):
         assert errs[r] is None, (r, errs[r], sps[r].error)
-        assert sps[r].calls == 2 * 6            # two exchanges per self-attention, 4 main + 2 adapter blocks
+        # two exchanges per self-attention launch; 4 main + 2 adapter blocks.  Sample lanes: block 0 of both chains runs
+        # batched, the other four blocks once per sample
+        assert sps[r].calls == (2 * 2 + 2 * 2 * 4 if lanes in (None, "2") else 2 * 6)
         assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
 
 

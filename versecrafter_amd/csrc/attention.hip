@@ -36,7 +36,7 @@ namespace {
 #define VC_ATTN_DEFER_MAX 8
 #endif
 #ifndef VC_ATTN_ROWSUM
-#define VC_ATTN_ROWSUM 4
+#define VC_ATTN_ROWSUM 0    // measured (round 2, tools/ab_attn.sh): 0: 1144 TF, 1: 1115, 2: 1126, 4: 1116 -- pinning the sums costs
 #endif
 #ifndef VC_ATTN_ABLATE
 #define VC_ATTN_ABLATE 0
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         const float mc = m_run * c;
         // ---- phase 1: MFMA S(t+1) = K(t+1).Q^T  ||  VALU P(t) = exp2(S(t) c - m c), row sums, bf16 pack ----
         if (MORE) qk(smem + P_KST + (PAR ^ 1) * TILE_BYTES, Sn);
-        // row sums: VC_ATTN_ROWSUM independent partial sums, reduced and pinned HERE -- left to itself hipcc sinks the whole
-        // 32-add dependency chain behind the next barrier, where no MFMA of this wave can cover it (0: the unpinned chain)
+        // row sums.  hipcc sinks this 32-add chain behind the next barrier; VC_ATTN_ROWSUM = n > 0 builds n independent partial
+        // sums pinned to this phase instead (A/B knob: every pinned form measured 1.5-2.5 % SLOWER, so 0 is the default)
         constexpr int NPS = VC_ATTN_ROWSUM > 0 ? VC_ATTN_ROWSUM : 1;
         float ps[NPS];
 #pragma unroll

@@ -47,7 +47,8 @@ thread_local std::string g_create_error;
 // scratch buffers + stream of one block chain.  Lane 0 = main chain on the caller's stream; lane 1 = GeoAdapter chain on
 // an engine-owned stream (used when the two chains run concurrently, see vc_forward).
 struct Lane {
-    int idx = 0;
+    int idx = 0;                    // which communicator / stream slot the lane uses
+    int b0 = 0, nb = 0;             // the samples of the batch this lane works on: [b0, b0 + nb)
     hipStream_t s = nullptr;
     void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
 };
@@ -94,7 +95,14 @@ struct vc_engine {
     void *x, *c, *c0, *patchA, *ctxpad, *ctxh, *ctx, *headmod, *ybuf, *yfull;
     void* hint[2];                  // hint ring (2 slots when the chains run concurrently)
     Lane lane[2];
-    bool dual = false;              // adapter chain on its own stream (sequence-parallel runs: hides the exchanges)
+    // how vc_forward spreads a step over HIP streams (sequence-parallel runs: one stream's kernels cover the other's exchanges)
+    //   0  one stream
+    //   1  "chain lanes": the GeoAdapter chain on its own stream, at most two blocks ahead of the main chain (2-slot hint ring)
+    //   2  "sample lanes" (B = 2, the CFG pair): sample 0 on the caller's stream, sample 1 on the engine's -- the two samples
+    //      never depend on each other, so both streams are busy for the whole step and each one's exchanges run beside the
+    //      other's GEMMs / attention; after block 0 of both chains (kept batched: the shared CFG prefix)
+    int lane_mode = 0;
+    bool dual = false;              // lane_mode == 1
     hipStream_t s_adp = nullptr;
     hipEvent_t ev_x = nullptr, ev_bp = nullptr;
     std::vector<hipEvent_t> ev_hint, ev_used;
@@ -343,13 +351,14 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
 int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, Lane& ln,
               hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr, bool shared_sa = false) {
     hipStream_t s = ln.s;
-    const int d = h->cfg.dim, f = h->cfg.ffn_dim, M = h->M, B = h->B, Lloc = h->Lloc, TL = h->cfg.text_len;
+    const int d = h->cfg.dim, f = h->cfg.ffn_dim, B = ln.nb, Lloc = h->Lloc, M = B * Lloc, TL = h->cfg.text_len;
     const int Bs = shared_sa ? 1 : B, Ms = Bs * Lloc;          // batch / rows of the self-attention half
+    const float* e0 = h->f_e0 + (int64_t)ln.b0 * 6 * d;        // this lane's samples
     const float eps = h->cfg.eps;
     const char* mod = (const char*)ln.mod;
     auto modp = [&](int j) { return (const void*)(mod + (int64_t)j * d * 2); };
     // e = modulation + e0  (WT.py:588)
-    VCCHK(h, vc_launch_modulation(w.modulation, h->f_e0, ln.mod, B, 6, d, 6 * d, d, s));
+    VCCHK(h, vc_launch_modulation(w.modulation, e0, ln.mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
     { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, Ms, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
     // q, k, v projections into [M, 3d]  (WT.py:385-387): one grouped launch (3 problems sharing A)
@@ -389,13 +398,13 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         memset(&a, 0, sizeof a);
         a.scale = 1.0f / sqrtf(128.0f);
         a.q = ln.qkv; a.q_bs = (int64_t)Lloc * d; a.q_ts = d; a.q_hs = 128;
-        a.k = w.ck; a.k_bs = (int64_t)TL * d; a.k_ts = d; a.k_hs = 128;
-        a.v = w.cv; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
+        a.k = (const char*)w.ck + (int64_t)ln.b0 * TL * d * 2; a.k_bs = (int64_t)TL * d; a.k_ts = d; a.k_hs = 128;
+        a.v = (const char*)w.cv + (int64_t)ln.b0 * TL * d * 2; a.v_bs = (int64_t)TL * d; a.v_ts = d; a.v_hs = 128;
         a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.B = B; a.H = h->cfg.num_heads; a.Lq = Lloc; a.Lk = TL; a.k_len = 0;
         if (B <= 8 && h->pad_merge) {             // the zero-padded prompt positions are identical K / V rows
             a.pad_merge = 1;
-            for (int i = 0; i < B; ++i) a.pad_from[i] = h->text_lens[i];
+            for (int i = 0; i < B; ++i) a.pad_from[i] = h->text_lens[ln.b0 + i];
         }
         VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_CROSS));
         VcGemmParams g = gemm(ln.attn, d, w.ca_o_w, w.ca_o_b, xs, d, M, d, d, VC_EPI_BIAS_RESID);
@@ -656,9 +665,12 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off += align_up(bytes, 256); return o; };
     const int64_t md = (int64_t)M * d * 2;
-    {   // default: dual lane (adapter chain on its own stream) only under sequence parallelism; VC_DUAL_LANE=0/1 forces it
+    {   // default: two streams only under sequence parallelism (sample lanes for the CFG pair, chain lanes otherwise);
+        // VC_DUAL_LANE = 0 / 1 / 2 forces a mode (tests, what-if timing)
         const char* dl = getenv("VC_DUAL_LANE");
-        h->dual = dl ? atoi(dl) == 1 : h->sp_exchange;
+        h->lane_mode = dl ? atoi(dl) : (h->sp_exchange ? (B == 2 ? 2 : 1) : 0);
+        if (h->lane_mode < 0 || h->lane_mode > 2 || (h->lane_mode == 2 && B != 2)) h->lane_mode = h->sp_exchange ? 1 : 0;
+        h->dual = h->lane_mode == 1;
     }
     const int nlanes = h->dual ? 2 : 1;
     const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md);
@@ -791,7 +803,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     { int r = time_embed(h, t, B, h->f_sin, h->f_h, h->f_e, h->f_e0, s); if (r != VC_OK) return r; }
 
     Lane& L0 = h->lane[0];
-    L0.idx = 0; L0.s = s;
+    L0.idx = 0; L0.s = s; L0.b0 = 0; L0.nb = B;
     if (run_main) {
         if (store_res) {                                     // ori_x = x.clone()  (VC.py:398)
             if (h->resid_cap[slot] < md) {                   // first use of the slot (or a larger batch): one-time allocation
@@ -808,15 +820,60 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         }
         const int NA = (int)h->gblocks.size();
         // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
-        auto adapter_block = [&](int n, Lane& la, int nslots) -> int {
+        // (on the rows of lane `la`'s samples)
+        auto adapter_block = [&](int n, Lane& la, int nslots, bool shared) -> int {
             const BlockW& gb = h->gblocks[n];
-            int r = run_block(h, gb, h->c, nullptr, 0.f, la, nullptr, nullptr, shared0 && n == 0);
+            const int64_t ro = (int64_t)la.b0 * Lloc * d * 2;
+            char* cc = (char*)h->c + ro;
+            int r = run_block(h, gb, cc, nullptr, 0.f, la, nullptr, nullptr, shared);
             if (r != VC_OK) return r;
-            VcGemmParams g = gemm(h->c, d, gb.after_w, gb.after_b, h->hint[n % nslots], d, M, d, d);
+            VcGemmParams g = gemm(cc, d, gb.after_w, gb.after_b, (char*)h->hint[n % nslots] + ro, d, la.nb * Lloc, d, d);
             VCCHK(h, p_gemm(h, g, la.s));
             return VC_OK;
         };
-        if (!h->dual) {
+        if (h->lane_mode == 2) {
+            // ---- sample lanes (B = 2) ----
+            // c = before_proj(c0) + x, then block 0 of both chains, batched on the caller's stream: the CFG pair enters them
+            // with identical rows, so their self-attention half is computed once (shared0)
+            {
+                const BlockW& g0 = h->gblocks[0];
+                VcGemmParams g = gemm(h->c0, d, g0.before_w, g0.before_b, h->c, d, M, d, d, VC_EPI_BIAS_RESID);
+                g.resid = h->x; g.ldr = d;
+                VCCHK(h, p_gemm(h, g, s));
+            }
+            int next_adapter = 0;
+            { int r = adapter_block(next_adapter++, L0, 1, shared0); if (r != VC_OK) return r; }      // 0 in geoada_layers
+            { int r = run_block(h, h->blocks[0], h->x, h->hint[0], geoada_context_scale, L0, nullptr, nullptr, shared0);
+              if (r != VC_OK) return r; }
+            // fork: sample 0 stays on the caller's stream, sample 1 moves to the engine's; both work in place on their rows of
+            // the same buffers (activations are [B][Lloc][.] with the sample outermost), each with its own communicator
+            Lane SL[2];
+            for (int b = 0; b < 2; ++b) {
+                Lane& v = SL[b];
+                v.idx = b; v.b0 = b; v.nb = 1; v.s = b == 0 ? s : h->s_adp;
+                const int64_t rows = (int64_t)b * Lloc;
+                v.tb = (char*)L0.tb + rows * d * 2; v.qkv = (char*)L0.qkv + rows * 3 * d * 2;
+                v.attn = (char*)L0.attn + rows * d * 2; v.hb = (char*)L0.hb + rows * c.ffn_dim * 2;
+                v.mod = (char*)L0.mod + (int64_t)b * 6 * d * 2;
+                v.send = (char*)L0.send + rows * 3 * d * 2; v.recv = (char*)L0.recv + rows * 3 * d * 2;
+            }
+            HIPCHK(h, hipEventRecord(h->ev_x, s));
+            HIPCHK(h, hipStreamWaitEvent(h->s_adp, h->ev_x, 0));
+            for (int i = 1; i < c.num_layers; ++i) {
+                const int hn = h->layer_to_hint[i];
+                if (hn >= 0)
+                    for (; next_adapter <= hn; ++next_adapter)
+                        for (int b = 0; b < 2; ++b) { int r = adapter_block(next_adapter, SL[b], 1, false); if (r != VC_OK) return r; }
+                for (int b = 0; b < 2; ++b) {
+                    const int64_t ro = (int64_t)b * Lloc * d * 2;
+                    int r = run_block(h, h->blocks[i], (char*)h->x + ro, hn >= 0 ? (char*)h->hint[0] + ro : nullptr,
+                                      geoada_context_scale, SL[b]);
+                    if (r != VC_OK) return r;
+                }
+            }
+            HIPCHK(h, hipEventRecord(h->ev_bp, h->s_adp));               // join
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_bp, 0));
+        } else if (!h->dual) {
             // c = before_proj(c0) + x   (VC.py:113-114)
             {
                 const BlockW& g0 = h->gblocks[0];
@@ -829,7 +886,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                 const int hn = h->layer_to_hint[i];
                 if (hn >= 0)
                     while (next_adapter <= hn) {             // adapter block n right before the layer that needs hint n
-                        int r = adapter_block(next_adapter, L0, 1);
+                        int r = adapter_block(next_adapter, L0, 1, shared0 && next_adapter == 0);
                         if (r != VC_OK) return r;
                         ++next_adapter;
                     }
@@ -842,7 +899,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             // stream, at most two blocks ahead of the main layer that consumes its hints (2-slot hint ring): while one
             // chain waits for an Ulysses exchange the other chain's kernels keep the GPU busy.
             Lane& L1 = h->lane[1];
-            L1.idx = 1; L1.s = h->s_adp;
+            L1.idx = 1; L1.s = h->s_adp; L1.b0 = 0; L1.nb = B;
             HIPCHK(h, hipEventRecord(h->ev_x, s));                       // x, e, e0 ready
             HIPCHK(h, hipStreamWaitEvent(L1.s, h->ev_x, 0));
             {
@@ -856,7 +913,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             int issued = 0;
             auto issue_adapter = [&](int n) -> int {                     // slot n%2 must have been consumed (hint n-2)
                 if (n >= 2) HIPCHK(h, hipStreamWaitEvent(L1.s, h->ev_used[n - 2], 0));
-                int r = adapter_block(n, L1, 2);
+                int r = adapter_block(n, L1, 2, shared0 && n == 0);
                 if (r != VC_OK) return r;
                 HIPCHK(h, hipEventRecord(h->ev_hint[n], L1.s));
                 return VC_OK;
