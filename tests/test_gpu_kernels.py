@@ -243,7 +243,7 @@ def test_attention_segmented_layout_equals_contiguous_bitwise(ops, S, Ls, k_len)
     assert torch.isfinite(got.float()).all() and torch.equal(got, want)
 
 
-@pytest.mark.parametrize("lens", [(77, 60), (1, 511), (0, 512), (300, 64), (510, 129)])
+@pytest.mark.parametrize("lens", [(77, 60), (1, 511), (0, 512), (300, 64), (510, 129), (200, 255), (64, 63), (127, 128)])
 def test_cross_attention_padded_key_folding(ops, lens):
     """T5 cross-attention attends over all 512 positions of a zero-padded prompt (WT.py:425-430): the padded K / V rows
     are identical, and folding them into one key with multiplicity n (log2 n added to its exponent) is the same softmax.
@@ -262,6 +262,21 @@ def test_cross_attention_padded_key_folding(ops, lens):
     want = O.attention(q.float(), k.float(), v.float(), None)
     assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="padmerge vs oracle")          # same bound as test_attention
     assert rel_l2(got, want) < 6e-3 and rel_l2(got, plain.float().cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("Lq,Lk,k_len", [(1300, 48, 0), (1024, 64, 0), (1111, 130, 0), (2049, 256, 0), (1300, 200, 77), (1300, 256, 193)])
+def test_short_key_attention_kernel(ops, Lq, Lk, k_len):
+    """Keys that fit in LDS whole (<= 256) with a long query axis take attn_short_kernel (K / V staged once per workgroup, the
+    query axis walked in 128-row trips): ragged query counts, partial last key tile, key-length mask -- against the oracle."""
+    rs = np.random.RandomState(Lq + Lk + k_len)
+    B, H = 2, 3
+    q = bf(rs_randn(rs, B, Lq, H, 128))
+    k, v = bf(rs_randn(rs, B, Lk, H, 128)), bf(rs_randn(rs, B, Lk, H, 128))
+    got = ops.attention(dev(q), dev(k), dev(v), k_len=k_len)
+    torch.cuda.synchronize()
+    want = O.attention(q.float(), k.float(), v.float(), [k_len] * B if k_len else None)
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="short-key attention")
+    assert rel_l2(got, want) < 6e-3
 
 
 def test_attention_large_logits_rescale(ops):

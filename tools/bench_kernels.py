@@ -61,6 +61,10 @@ def bench_attn():
     med, mn = timeit(lambda: ops.attention(qc, kc, vc, out=out), rounds=4, inner=2)
     fl = 4.0 * B * H * L * 512 * 128
     print(f"attn cross Lk=512: median {med:.3f} ms ({fl / med / 1e9:.0f} TF)", flush=True)
+    med, mn = timeit(lambda: ops.attention_padmerge(qc, kc, vc, [60, 77]), rounds=4, inner=2)
+    by = 2.0 * 2 * B * H * L * 128
+    print(f"attn cross, padded keys folded (60 / 77-token prompts, the engine's call): median {med:.3f} ms min {mn:.3f} ms "
+          f"({by / mn / 1e6:.0f} GB/s of Q read + O write)", flush=True)
 
 
 def bench_attn_seg():

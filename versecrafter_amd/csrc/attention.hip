@@ -376,6 +376,178 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     }
 }
 
+// =====================================================================================================
+// Short key sequences (T5 cross-attention, WT.py:425-430: 512 prompt positions of which the zero-padded tail folds into one key,
+// so 2-4 tiles of 64 keys remain): the whole K and V of one (batch, head) fit in LDS.  A workgroup of 4 waves stages them ONCE
+// (swizzled images as above) and then walks a chunk of the query axis, 32 rows per wave per trip, with no further barrier:
+// per tile QK^T (16 MFMA), exact online softmax, PV (16 MFMA).  No software pipeline and nothing to spill -- the kernel is bound
+// by reading Q and writing O once (the pipelined kernel's 2-tile case was all prologue / tail and spilled 893 VGPRs).
+// =====================================================================================================
+constexpr int SHORT_MAX_TILES = 4;
+
+template <bool MERGE>
+__global__ __launch_bounds__(256, 2) void attn_short_kernel(VcAttnParams p, int nchunks, int chunk_rows, int nt_lds, int nwork) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per_xcd = gridDim.x >> 3;
+    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (id >= nwork) return;
+    const int bh = id / nchunks, chunk = id - bh * nchunks;
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+    const bf16_t* kp = (const bf16_t*)p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+    const bf16_t* vp = (const bf16_t*)p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+    bf16_t* op = (bf16_t*)p.out + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
+
+    int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
+    float pad_bias = 0.f;
+    if (MERGE) {
+        const int from = p.pad_from[b];
+        if (from >= 0 && from < p.Lk - 1) {
+            k_len = from + 1;
+            pad_bias = log2f((float)(p.Lk - from)) / (p.scale * 1.4426950408889634f);
+        }
+    }
+    const int nt = (k_len + KT - 1) / KT;              // <= nt_lds (launcher)
+    char* kimg = smem;
+    char* vimg = smem + nt_lds * TILE_BYTES;
+    // ---- stage K and V of this (batch, head): 16-byte chunks, consecutive lanes on consecutive chunks of a row ----
+    for (int idx = tid; idx < nt * KT * 16; idx += 256) {
+        const int row = idx >> 4, ch = idx & 15;       // row = key index (tile-major: tile = row / 64)
+        const int key = row < p.Lk ? row : p.Lk - 1;
+        const int tr = row & (KT - 1), tile = row >> 6;
+        *(uint4*)(kimg + tile * TILE_BYTES + k_off(tr, ch)) = *(const uint4*)(kp + (int64_t)key * p.k_ts + ch * 8);
+        *(uint4*)(vimg + tile * TILE_BYTES + v_off(tr, ch)) = *(const uint4*)(vp + (int64_t)key * p.v_ts + ch * 8);
+    }
+    __syncthreads();
+
+    AttnLaneConst lc;
+    {
+        const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) lc.koff[ks] = k_off(r, ks * 2 + h);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                lc.voff[db][hf] = v_off(4 * (g >> 1) + q4 + 8 * hf, db * 4 + 2 * (g & 1) + (p4 >> 1)) + 8 * (p4 & 1);
+    }
+    const float c = p.scale * 1.4426950408889634f;
+    const int row_end = min(p.Lq, (chunk + 1) * chunk_rows);
+    for (int q0 = chunk * chunk_rows + wave * 32; q0 < row_end; q0 += 128) {
+        const int q_row = q0 + r;
+        const int q_row_c = q_row < p.Lq ? q_row : p.Lq - 1;
+        bf16x8 qf[8];
+        {
+            const bf16_t* qrow = qp + (int64_t)q_row_c * p.q_ts + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 16);
+        }
+        f32x16 O[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[i][e] = 0.f;
+        float m_run = -1e30f, l_run = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            f32x16 S[2];
+            const char* kbuf = kimg + t * TILE_BYTES;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
+                    S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
+                }
+            }
+            if (t == nt - 1) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (key >= k_len) S[kb][e] = -1e30f;
+                        else if (MERGE && key == k_len - 1) S[kb][e] += pad_bias;
+                    }
+            }
+            float mx = S[0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[0][e]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[1][e]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            const float m_new = fmaxf(m_run, fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+            if (__any(m_new > m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = m_run * c;
+            bf16x8 pf[4];
+            float ps = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pe = __builtin_amdgcn_exp2f(S[s >> 1][8 * (s & 1) + j] * c - mc);
+                    ps += pe;
+                    pf[s][j] = (__bf16)pe;
+                }
+            l_run += ps;
+            const char* vbuf = vimg + t * TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][0] + s * 4096));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][1] + s * 4096));
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], O[db], 0, 0, 0);
+                }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q_row < p.Lq) {
+            bf16_t* orow = op + (int64_t)q_row * p.o_ts + 4 * h;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4] = {O[db][4 * g4] * inv, O[db][4 * g4 + 1] * inv, O[db][4 * g4 + 2] * inv,
+                                  O[db][4 * g4 + 3] * inv};
+                    *(uint2*)(orow + db * 32 + 8 * g4) = pack4(v);
+                }
+        }
+    }
+}
+
+template <bool MERGE>
+int launch_attn_short(const VcAttnParams& p, int nt_lds, hipStream_t stream) {
+    const int lds = nt_lds * 2 * TILE_BYTES;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!vc_set_lds_once(attr_done, (const void*)attn_short_kernel<MERGE>, SHORT_MAX_TILES * 2 * TILE_BYTES)) return VC_E_HIP;
+    // ~3 workgroups per CU; a chunk is a whole number of 128-row trips
+    const int bh = p.B * p.H;
+    int nchunks = (768 + bh - 1) / bh;
+    const int max_chunks = (p.Lq + 127) / 128;
+    if (nchunks > max_chunks) nchunks = max_chunks;
+    if (nchunks < 1) nchunks = 1;
+    const int chunk_rows = ((p.Lq + nchunks - 1) / nchunks + 127) / 128 * 128;
+    nchunks = (p.Lq + chunk_rows - 1) / chunk_rows;
+    const int nwork = bh * nchunks;
+    const int grid = (nwork + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_short_kernel<MERGE>, dim3(grid), dim3(256), lds, stream, p, nchunks, chunk_rows, nt_lds, nwork);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
 template <bool SEG, int NW, bool MERGE = false>
 int launch_attn_pipe(const VcAttnParams& p, hipStream_t stream) {
     constexpr int QB = NW * 32;
@@ -405,8 +577,16 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
     // (T5 cross-attention, 512 keys) are prologue-dominated and run better with twice as many, smaller workgroups
     if (p.pad_merge) {
         if (p.seg_len > 0 || p.k_len > 0 || p.B > 8) return VC_E_UNSUPPORTED;
+        int nt_max = 0;                                  // key tiles left after folding the padded tail, worst sample
+        for (int i = 0; i < p.B; ++i) {
+            const int from = p.pad_from[i];
+            const int kl = (from >= 0 && from < p.Lk - 1) ? from + 1 : p.Lk;
+            nt_max = nt_max > (kl + KT - 1) / KT ? nt_max : (kl + KT - 1) / KT;
+        }
+        if (nt_max <= SHORT_MAX_TILES && p.Lq >= 128) return launch_attn_short<true>(p, nt_max, stream);
         return launch_attn_pipe<false, 4, true>(p, stream);
     }
+    if (p.seg_len == 0 && p.Lk <= SHORT_MAX_TILES * KT && p.Lq >= 1024) return launch_attn_short<false>(p, (p.Lk + KT - 1) / KT, stream);
     if (p.Lk >= 2048) return p.seg_len > 0 ? launch_attn_pipe<true, 8>(p, stream) : launch_attn_pipe<false, 8>(p, stream);
     return p.seg_len > 0 ? launch_attn_pipe<true, 4>(p, stream) : launch_attn_pipe<false, 4>(p, stream);
 }
