@@ -436,14 +436,24 @@ __global__ __launch_bounds__(256, 2) void attn_short_kernel(VcAttnParams p, int 
     }
     const float c = p.scale * 1.4426950408889634f;
     const int row_end = min(p.Lq, (chunk + 1) * chunk_rows);
-    for (int q0 = chunk * chunk_rows + wave * 32; q0 < row_end; q0 += 128) {
-        const int q_row = q0 + r;
-        const int q_row_c = q_row < p.Lq ? q_row : p.Lq - 1;
-        bf16x8 qf[8];
-        {
-            const bf16_t* qrow = qp + (int64_t)q_row_c * p.q_ts + 8 * h;
+    // the Q rows of the NEXT trip are requested before this trip's arithmetic (the kernel is bound by these reads and the O
+    // writes: one more trip of loads in flight per wave)
+    auto load_q = [&](int q0, bf16x8 (&dst)[8]) {
+        const int row = q0 + r < p.Lq ? q0 + r : p.Lq - 1;
+        const bf16_t* qrow = qp + (int64_t)row * p.q_ts + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 16);
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = *(const bf16x8*)(qrow + ks * 16);
+    };
+    bf16x8 qf[8], qn[8];
+    const int q_first = chunk * chunk_rows + wave * 32;
+    if (q_first < row_end) load_q(q_first, qf);
+    for (int q0 = q_first; q0 < row_end; q0 += 128) {
+        const int q_row = q0 + r;
+        const bool more = q0 + 128 < row_end;
+        if (more) {
+            load_q(q0 + 128, qn);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qn[ks]));      // issue the loads here, not where they are used
         }
         f32x16 O[4];
 #pragma unroll
@@ -515,16 +525,29 @@ __global__ __launch_bounds__(256, 2) void attn_short_kernel(VcAttnParams p, int 
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
-        if (q_row < p.Lq) {
-            bf16_t* orow = op + (int64_t)q_row * p.o_ts + 4 * h;
+        // Epilogue: a lane holds 8-byte pieces (4 dims) at dims db*32 + 8*g4 + 4*h; the two halves of the wave (lane r, r + 32)
+        // hold the neighbouring pieces of the same row.  One permlane32 swap per register pairs them up -- lanes 0-31 keep the
+        // even g4 of both halves, lanes 32-63 the odd ones -- so that every lane stores 16 contiguous bytes: 8 dwordx4 stores
+        // instead of 16 dwordx2 (the row-per-lane store tail is issue-bound: MI355X_MICROARCH.md, attention epilogue).
+        {
+            bf16_t* orow = op + (int64_t)q_row * p.o_ts + 8 * h;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    float v[4] = {O[db][4 * g4] * inv, O[db][4 * g4 + 1] * inv, O[db][4 * g4 + 2] * inv,
-                                  O[db][4 * g4 + 3] * inv};
-                    *(uint2*)(orow + db * 32 + 8 * g4) = pack4(v);
+                for (int j = 0; j < 2; ++j) {
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = O[db][8 * j + e] * inv; vb[e] = O[db][8 * j + 4 + e] * inv; }
+                    const uint2 pa = pack4(va), pb = pack4(vb);       // g4 = 2j and g4 = 2j + 1 of this half
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                    // lanes 0-31: {own 2j, partner's 2j}; lanes 32-63: {partner's 2j+1, own 2j+1}
+                    if (q_row < p.Lq) *(uint4*)(orow + db * 32 + 16 * j) = uint4{sx[0], sy[0], sx[1], sy[1]};
                 }
+        }
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = qn[ks];
         }
     }
 }
@@ -534,9 +557,10 @@ int launch_attn_short(const VcAttnParams& p, int nt_lds, hipStream_t stream) {
     const int lds = nt_lds * 2 * TILE_BYTES;
     static std::atomic<uint64_t> attr_done{0};
     if (!vc_set_lds_once(attr_done, (const void*)attn_short_kernel<MERGE>, SHORT_MAX_TILES * 2 * TILE_BYTES)) return VC_E_HIP;
-    // ~3 workgroups per CU; a chunk is a whole number of 128-row trips
+    // ~10 workgroups per CU (two are resident at a time: five rounds, so the ragged last round costs little; staging K / V
+    // again per workgroup is 32-64 KB against 256 KB of Q + O per trip); a chunk is a whole number of 128-row trips
     const int bh = p.B * p.H;
-    int nchunks = (768 + bh - 1) / bh;
+    int nchunks = (2560 + bh - 1) / bh;
     const int max_chunks = (p.Lq + 127) / 128;
     if (nchunks > max_chunks) nchunks = max_chunks;
     if (nchunks < 1) nchunks = 1;
