@@ -17,7 +17,7 @@ def find(d, suffix):
 
 
 def short(name):
-    for k in ("attn_fwd_pipe_kernel", "attn_fwd_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "t5_attention_kernel", "geoada_context_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
+    for k in ("attn_fwd_pipe_kernel", "attn_short_kernel", "attn_fwd_kernel", "conv_igemm_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "t5_attention_kernel", "geoada_context_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
               "unpatchify_kernel", "small_linear_kernel", "modulation_kernel", "axpy_kernel", "copy_strided_kernel"):
         if k in name:
             if k == "gemm_bf16_kernel":
@@ -54,13 +54,16 @@ def main():
             rows = list(csv.DictReader(open(find(d, "_counter_collection.csv"))))
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
             seen = collections.Counter()
+            # cross-attention has its own kernel (attn_short_kernel) when the folded prompt fits in LDS: then every launch of
+            # the pipelined kernel is a self-attention; otherwise the two alternate inside every DiT block
+            alternate = not any("attn_short_kernel" in r["Kernel_Name"] for r in rows)
             for r in rows:
                 if r["Counter_Name"] != ctr:
                     continue
                 k = short(r["Kernel_Name"])
-                if k.startswith("attn_fwd"):          # launches alternate self / cross inside every DiT block
+                if k.startswith("attn_fwd"):
                     base = k
-                    k += "[self]" if seen[base] % 2 == 0 else "[cross]"
+                    k += "[self]" if (not alternate or seen[base] % 2 == 0) else "[cross]"
                     seen[base] += 1
                 agg[k][ctr] += float(r["Counter_Value"])
                 if ctr == "FETCH_SIZE":
