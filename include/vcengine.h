@@ -32,7 +32,7 @@ extern "C" {
 #define VC_E_NOMEM (-4)
 #define VC_E_UNSUPPORTED (-5) /* shape outside what the kernels implement            */
 
-#define VC_ABI_VERSION 2
+#define VC_ABI_VERSION 3
 #define VC_MAX_GEOADA_LAYERS 64
 
 typedef struct vc_engine vc_engine;
@@ -215,6 +215,35 @@ int vc_t5_relative_bucket(int rel, int num_buckets, int max_distance);
 const char* vc_t5_last_error(const vc_t5* h);
 int64_t vc_t5_workspace_bytes(const vc_t5* h);
 void vc_t5_destroy(vc_t5* h);
+
+/* ---- Wan2.1 video VAE ----------------------------------------------------------------------------
+ * Replaces AutoencoderKLWan (videox_fun, un-vendored; origin Wan2.1 wan/modules/vae.py) as the reference's pipeline uses it:
+ * `vae.encode(frames)[0].mode()` for each control video (pipeline_wan_versecrafter.py:397-438) and `vae.decode(latents).sample`
+ * (pipeline_wan_versecrafter.py:550-555), constructed at inference/versecrafter_inference.py:220-236 with
+ * config/wan2.1/wan_civitai.yaml:8-13.  PARITY UNPINNED: restated from the published architecture (oracle/vae_oracle.py).
+ * Weights are borrowed device pointers (bf16) addressed by the upstream state-dict keys (without VideoX-Fun's "model." prefix):
+ *   encoder.conv1, encoder.downsamples.N.{residual.{0,3}.gamma, residual.{2,6}, shortcut, resample.1, time_conv},
+ *   encoder.middle.{0,2}.*, encoder.middle.1.{norm.gamma, to_qkv, proj}, encoder.head.{0.gamma, 2}, conv1, conv2, decoder.* ;
+ * they are re-packed once (tap-major, channels padded to 64) into library-owned memory at the first encode / decode.
+ * The workspace is allocated per call and freed before returning (once per video; vc_vae_workspace_bytes = last call's). */
+typedef struct vc_vae_config {
+    int32_t dim, z_dim;                 /* 96, 16 */
+    int32_t dim_mult[4];                /* 1, 2, 4, 4 */
+    int32_t num_res_blocks;             /* 2 (the decoder uses one more per level) */
+    int32_t temporal_downsample[3];     /* 0, 1, 1 */
+} vc_vae_config;
+typedef struct vc_vae vc_vae;
+int vc_vae_create(const vc_vae_config* cfg, vc_vae** out);
+int vc_vae_load_weight(vc_vae* h, const char* key, const void* dev_ptr, int ndim, const int64_t* shape);
+int vc_vae_missing_weights(const vc_vae* h);
+/* x: DEVICE bf16 [3][F][H][W] in [-1, 1], F = 1 + 4n, H and W multiples of 16; out: DEVICE bf16 [z_dim][1 + n][H/8][W/8] = the
+ * posterior mean, normalised with the published per-channel latent mean / std (what `.mode()` returns upstream). */
+int vc_vae_encode(vc_vae* h, const void* x, void* out, int F, int H, int W, void* stream);
+/* z: DEVICE bf16 [z_dim][T][h][w] (normalised latents); out: DEVICE bf16 [3][1 + 4 (T - 1)][8h][8w], clamped to [-1, 1]. */
+int vc_vae_decode(vc_vae* h, const void* z, void* out, int T, int h_lat, int w_lat, void* stream);
+const char* vc_vae_last_error(const vc_vae* h);
+int64_t vc_vae_workspace_bytes(const vc_vae* h);
+void vc_vae_destroy(vc_vae* h);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ VC_E_INVALID, VC_E_HIP, VC_E_STATE, VC_E_NOMEM, VC_E_UNSUPPORTED = -1, -2, -3, -
 VC_FWD_RUN_MAIN_BLOCKS, VC_FWD_STORE_RESIDUAL, VC_FWD_USE_RESIDUAL, VC_FWD_SHARED_CFG_INPUT = 1, 2, 4, 8
 VC_FWD_RESIDUAL_UNCOND = 16
 VC_MAX_GEOADA_LAYERS = 64
-VC_ABI_VERSION = 2
+VC_ABI_VERSION = 3
 VC_RCCL_UNIQUE_ID_BYTES = 128
 VC_SP_FORCE_EXCHANGE = 1
 
@@ -26,6 +26,11 @@ class vc_config(C.Structure):
                 ("text_dim", C.c_int32), ("text_len", C.c_int32), ("freq_dim", C.c_int32),
                 ("eps", C.c_float), ("num_geoada_layers", C.c_int32),
                 ("geoada_layers", C.c_int32 * VC_MAX_GEOADA_LAYERS)]
+
+
+class vc_vae_config(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("z_dim", C.c_int32), ("dim_mult", C.c_int32 * 4), ("num_res_blocks", C.c_int32),
+                ("temporal_downsample", C.c_int32 * 3)]
 
 
 class vc_t5_config(C.Structure):
@@ -72,6 +77,14 @@ SYMBOLS = {
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
     "vc_op_geoada_context": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vc_op_unipc_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, C.POINTER(_F), _I, _P]),
+    "vc_vae_create": (_I, [C.POINTER(vc_vae_config), C.POINTER(_P)]),
+    "vc_vae_load_weight": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L)]),
+    "vc_vae_missing_weights": (_I, [_P]),
+    "vc_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vc_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vc_vae_last_error": (C.c_char_p, [_P]),
+    "vc_vae_workspace_bytes": (_L, [_P]),
+    "vc_vae_destroy": (None, [_P]),
     "vc_t5_create": (_I, [C.POINTER(vc_t5_config), C.POINTER(_P)]),
     "vc_t5_load_weight": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L)]),
     "vc_t5_encode": (_I, [_P, _P, _P, _P, _I, _I, _P]),
