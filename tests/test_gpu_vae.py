@@ -73,3 +73,24 @@ def test_errors_and_contract():
         m.encode(torch.zeros(1, 3, 5, 32, 32, dtype=torch.bfloat16))                     # CPU tensor
     a = m.encode(torch.zeros(1, 3, 5, 32, 32, device="cuda", dtype=torch.bfloat16))
     assert a.latent_dist.mode().shape == (1, 16, 2, 4, 4) and m.workspace_bytes() > 0
+
+
+def test_production_width_small_clip_vs_oracle():
+    """The published widths (dim 96 -> 96 / 192 / 384 / 384 channels, 127 M parameters: channel padding 96 -> 128, 64- and
+    128-column tiles, q|k|v of 3 x 384, time-doubling convs of 768 columns) on a 5-frame 64x64 clip the CPU oracle finishes
+    in seconds: encode, decode, and the encode -> decode round trip shape contract."""
+    cfg, Wf, m = make(dict(dim=96, z_dim=16), 11)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(1, 3, 5, 64, 64, generator=g) * 2 - 1).bfloat16()
+    got = m.encode(x.cuda())[0].mode()
+    with torch.no_grad():
+        want = V.encode(Wf, cfg, x.float())
+    e1 = rel(got, want)
+    z = torch.randn(1, 16, 2, 8, 8, generator=g).bfloat16()
+    dec = m.decode(z.cuda()).sample
+    with torch.no_grad():
+        wdec = V.decode(Wf, cfg, z.float())
+    e2 = rel(dec, wdec)
+    print(f"production width: encode rel L2 {e1:.4g}, decode rel L2 {e2:.4g}")
+    assert got.shape == (1, 16, 2, 8, 8) and dec.shape == (1, 3, 5, 64, 64)
+    assert e1 < 3e-2 and e2 < 3e-2
