@@ -225,7 +225,9 @@ void vc_t5_destroy(vc_t5* h);
  *   encoder.conv1, encoder.downsamples.N.{residual.{0,3}.gamma, residual.{2,6}, shortcut, resample.1, time_conv},
  *   encoder.middle.{0,2}.*, encoder.middle.1.{norm.gamma, to_qkv, proj}, encoder.head.{0.gamma, 2}, conv1, conv2, decoder.* ;
  * they are re-packed once (tap-major, channels padded to 64) into library-owned memory at the first encode / decode.
- * The workspace is allocated per call and freed before returning (once per video; vc_vae_workspace_bytes = last call's). */
+ * The workspace (six buffers of the largest activation: ~70 GB for an 81-frame 480p decode) is allocated at the first call that
+ * needs it and kept -- a video takes four encodes and one decode, and allocating tens of GB costs seconds -- until
+ * vc_vae_release_workspace or vc_vae_destroy; encode / decode return without a host sync. */
 typedef struct vc_vae_config {
     int32_t dim, z_dim;                 /* 96, 16 */
     int32_t dim_mult[4];                /* 1, 2, 4, 4 */
@@ -243,6 +245,7 @@ int vc_vae_encode(vc_vae* h, const void* x, void* out, int F, int H, int W, void
 int vc_vae_decode(vc_vae* h, const void* z, void* out, int T, int h_lat, int w_lat, void* stream);
 const char* vc_vae_last_error(const vc_vae* h);
 int64_t vc_vae_workspace_bytes(const vc_vae* h);
+int vc_vae_release_workspace(vc_vae* h);
 void vc_vae_destroy(vc_vae* h);
 
 #ifdef __cplusplus

@@ -400,7 +400,8 @@ struct vc_vae {
     std::vector<void*> owned;                                          // device allocations of packed weights
     bool packed = false;
     float *mean = nullptr, *inv_std = nullptr;
-    int64_t ws_bytes = 0;
+    char* ws = nullptr;               // workspace kept between calls (a video needs 4 encodes and a decode; allocating tens of
+    int64_t ws_bytes = 0;             // GB costs seconds) until vc_vae_release_workspace / vc_vae_destroy
     std::string err;
 };
 
@@ -785,6 +786,7 @@ void vc_vae_destroy(vc_vae* h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
     for (void* p : h->owned) (void)hipFree(p);
+    if (h->ws) (void)hipFree(h->ws);
     if (h->mean) (void)hipFree(h->mean);
     if (h->inv_std) (void)hipFree(h->inv_std);
     delete h;
@@ -812,6 +814,13 @@ int vc_vae_missing_weights(const vc_vae* h) {
 }
 
 int64_t vc_vae_workspace_bytes(const vc_vae* h) { return h ? h->ws_bytes : 0; }
+
+int vc_vae_release_workspace(vc_vae* h) {
+    if (!h) return VC_E_INVALID;
+    if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); }
+    h->ws = nullptr; h->ws_bytes = 0;
+    return VC_OK;
+}
 
 }  // extern "C"
 
@@ -968,14 +977,17 @@ int run_sized(vc_vae* h, hipStream_t s, Walk walk) {
     R.h = h; R.s = s; R.nslots = VAE_SLOTS; R.busy.assign(VAE_SLOTS, 0);
     R.slot_bytes = (D.need + 4095) / 4096 * 4096;
     const int64_t total = R.slot_bytes * R.nslots;
-    if (hipMalloc(&R.ws, (size_t)total) != hipSuccess) {
-        (void)hipGetLastError();
-        return vfail(h, VC_E_NOMEM, "hipMalloc of the %lld-byte VAE workspace failed", (long long)total);
+    if (h->ws_bytes < total) {
+        if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
+        if (hipMalloc(&h->ws, (size_t)total) != hipSuccess) {
+            (void)hipGetLastError();
+            h->ws = nullptr;
+            return vfail(h, VC_E_NOMEM, "hipMalloc of the %lld-byte VAE workspace failed", (long long)total);
+        }
+        h->ws_bytes = total;
     }
-    h->ws_bytes = total;
+    R.ws = h->ws;
     const int rc = walk(R);
-    (void)hipStreamSynchronize(s);           // the workspace is freed below: once per video, not on the step path
-    (void)hipFree(R.ws);
     if (rc != VC_OK && h->err.empty()) return vfail(h, rc, "VAE pass failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     return rc;
 }

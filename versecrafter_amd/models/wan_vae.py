@@ -271,6 +271,11 @@ class AutoencoderKLWan(nn.Module):
     def workspace_bytes(self):
         return 0 if self._engine is None else int(_lib.load().vc_vae_workspace_bytes(self._engine))
 
+    def release_workspace(self):
+        """Give the engine's activation buffers (tens of GB at production sizes) back; the next encode / decode re-allocates."""
+        if self._engine is not None:
+            _lib.load().vc_vae_release_workspace(self._engine)
+
     def __del__(self):
         try:
             if self._engine is not None:
