@@ -6,10 +6,13 @@ reference hard-codes at module level (:89-161) are exposed as extra flags with i
 reference does (`torchrun --nproc-per-node=N inference/versecrafter_inference.py ...`); ulysses_degree*ring_degree
 must equal N (the hybrid is run as pure Ulysses of that degree).
 
-The Wan VAE, the umT5 text encoder and the mp4 reader/writer belong to third-party packages that are outside this
-build.  When `videox_fun` is importable they are used exactly as the reference does; otherwise run
-with --synthetic_inputs (random control latents / prompt embeddings of the right shapes, latents saved as .safetensors)
-to exercise the denoising engine end to end.
+A full run mirrors the reference's flow (CLI.py:187-465): DiT + GeoAdapter from --transformer_path, the Wan VAE and the umT5
+encoder from --model_name (or --vae_path / --text_encoder_path), the four control maps + merged mask + first frame from
+--rendering_maps_path / --input_image_path, the video written to --save_path.  All three models run on the HIP engine
+(versecrafter_amd.models).  The build image has no video codec: control maps are read from frame dumps next to the .mp4 files
+(or through any importable decoder) and the result is written as .mp4 only when a writer is importable, else as a uint8 frame
+dump -- see versecrafter_amd/utils/video_io.py.  --synthetic_inputs runs the denoising engine on random control latents /
+prompt embeddings of the right shapes (no VAE, no T5, latents saved as .safetensors).
 """
 import argparse
 import os
@@ -70,9 +73,16 @@ def parse_args(argv=None):
                    help="umT5 checkpoint (models_t5_umt5-xxl-enc-bf16.pth or .safetensors): encode --prompt and the fixed negative prompt "
                         "with the HIP text encoder instead of random embeddings (needs --tokenizer_path)")
     p.add_argument("--tokenizer_path", type=str, default=None, help="local directory of the google/umt5-xxl tokenizer files")
+    p.add_argument("--prompt_embeds_path", type=str, default=None,
+                   help=".safetensors with 'prompt_embeds' [n,4096] and 'negative_prompt_embeds' [m,4096] (umT5 outputs computed "
+                        "elsewhere): used instead of --text_encoder_path")
+    p.add_argument("--vae_path", type=str, default=None,
+                   help="Wan2.1_VAE.pth / .safetensors (default: <model_name>/Wan2.1_VAE.pth, wan_civitai.yaml:9)")
+    p.add_argument("--vae_kwargs", type=str, default="{}", help="JSON overrides of the VAE hyper-parameters (tests: {\"dim\": 32})")
+    p.add_argument("--output_latents", type=int, default=0, help="1: also save the final latents as .safetensors")
     p.add_argument("--control_latents_path", type=str, default=None,
                    help=".safetensors with 'geoada_latents' [64,T,h,w] (VAE latents of the 4 control videos) and "
-                        "'mask_video' [1,F,H,W] (merged mask) -- stands in for the out-of-scope Wan VAE encode")
+                        "'mask_video' [1,F,H,W] (merged mask): skips the VAE encode of the control maps")
     return p.parse_args(argv)
 
 
@@ -100,6 +110,12 @@ def main(argv=None):
             low_cpu_mem_usage=True, torch_dtype=weight_dtype).to(device)
 
     vae = text_encoder = tokenizer = None
+    vae_path = args.vae_path or os.path.join(args.model_name, "Wan2.1_VAE.pth")
+    if not args.synthetic_inputs and os.path.isfile(vae_path):                      # CLI.py:220-223
+        import json
+        from versecrafter_amd.models import AutoencoderKLWan
+        vae = AutoencoderKLWan.from_pretrained(vae_path, additional_kwargs=dict(
+            temporal_compression_ratio=4, spatial_compression_ratio=8, **json.loads(args.vae_kwargs))).to(weight_dtype)
     if args.text_encoder_path:                                                      # CLI.py:238-249
         if not args.tokenizer_path:
             raise SystemExit("--text_encoder_path needs --tokenizer_path (local google/umt5-xxl tokenizer files)")
@@ -110,10 +126,12 @@ def main(argv=None):
             args.text_encoder_path, additional_kwargs=dict(vocab=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64,
                                                            num_layers=24, num_buckets=32, shared_pos=False, dropout=0.0),
             low_cpu_mem_usage=True, torch_dtype=weight_dtype).eval()
-    if not args.synthetic_inputs and not (args.text_encoder_path and args.control_latents_path):
-        raise SystemExit("a real run needs --text_encoder_path/--tokenizer_path and --control_latents_path (the Wan VAE and "
-                         "mp4 decoding belong to the third-party VideoX-Fun package and are not part of this build); "
-                         "otherwise pass --synthetic_inputs")
+    if not args.synthetic_inputs and text_encoder is None and not args.prompt_embeds_path:
+        raise SystemExit("a real run needs --text_encoder_path and --tokenizer_path (umT5 checkpoint + local tokenizer files) or "
+                         "--prompt_embeds_path; otherwise pass --synthetic_inputs")
+    if not args.synthetic_inputs and vae is None and not args.control_latents_path:
+        raise SystemExit(f"no VAE checkpoint at {vae_path}: pass --vae_path (or --control_latents_path for pre-encoded control "
+                         "maps, or --synthetic_inputs)")
 
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)  # CLI.py:252-261
     pipeline = WanVerseCrafterPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae,
@@ -136,6 +154,31 @@ def main(argv=None):
         from safetensors.torch import load_file
         cl = load_file(args.control_latents_path)
         control = dict(geoada_latents=[cl["geoada_latents"]], mask_video=cl["mask_video"][None].float())
+    elif not args.synthetic_inputs:
+        # CLI.py:351-403: four control maps, the merged mask (channel 0, frame 0 cleared), the first frame pasted into map 0
+        from versecrafter_amd.utils.video_io import read_image, read_video
+        if not os.path.isdir(args.rendering_maps_path):
+            raise SystemExit(f"Annotation path not found: {args.rendering_maps_path}")
+        size = (height, width)
+        control_videos = []
+        for name in ("background_RGB.mp4", "background_depth.mp4", "3D_gaussian_RGB.mp4", "3D_gaussian_depth.mp4"):
+            try:
+                control_videos.append(read_video(os.path.join(args.rendering_maps_path, name), args.video_length, size))
+            except FileNotFoundError:
+                # the reference appends a zero placeholder only after the first map (CLI.py:378-382) and then fails on the
+                # channel count when map 0 is the missing one; say what is missing instead
+                if not control_videos:
+                    raise SystemExit(f"control map {name} is missing under {args.rendering_maps_path} (the reference needs all "
+                                     "four: geoada_in_dim = 4 x 16 latent channels + 64 mask planes)")
+                print(f"Warning: Control video not found: {name}")
+                control_videos.append(torch.zeros_like(control_videos[0]))
+        try:
+            mask = read_video(os.path.join(args.rendering_maps_path, "merged_mask.mp4"), args.video_length, size)[:, :1]
+            mask[:, :, 0] = 0.0
+        except FileNotFoundError:
+            mask = torch.ones_like(control_videos[0][:, :1]) * 255
+        control_videos[0][:, :, 0] = read_image(args.input_image_path, size).squeeze(2)
+        control = dict(control_video=control_videos, mask_video=mask)
     else:
         ctrl = torch.randn(64, T, h, w, generator=g)
         mask = (torch.rand(64, T, h, w, generator=g) < 0.5).float()
@@ -143,24 +186,42 @@ def main(argv=None):
         control = dict(geoada_latents=[ctrl], mask_latents=[mask])
     if text_encoder is not None:
         embeds = dict(prompt=args.prompt, negative_prompt=NEGATIVE_PROMPT)                     # CLI.py:421-423
+    elif args.prompt_embeds_path:
+        from safetensors.torch import load_file
+        pe = load_file(args.prompt_embeds_path)
+        embeds = dict(prompt_embeds=[pe["prompt_embeds"]], negative_prompt_embeds=[pe["negative_prompt_embeds"]])
     else:
         embeds = dict(prompt_embeds=[torch.randn(77, transformer.text_dim, generator=g)],
                       negative_prompt_embeds=[torch.randn(60, transformer.text_dim, generator=g)])
     t0 = time.time()
+    latents_box = {}
+
+    def keep_latents(pipe, i, t, kw):                     # the final latents, for --output_latents / runs without a VAE
+        latents_box["latents"] = kw["latents"]
+        return {}
+    decode = vae is not None
     sample = pipeline(height=height, width=width, num_frames=args.video_length, generator=generator,
                       guidance_scale=args.guidance_scale, num_inference_steps=args.num_inference_steps,
-                      shift=args.shift, geoada_context_scale=args.geoada_context_scale, output_type="latent",
+                      shift=args.shift, geoada_context_scale=args.geoada_context_scale,
+                      output_type="numpy" if decode else "latent", callback_on_step_end=keep_latents,
                       **control, **embeds).videos
     torch.cuda.synchronize()
     dt = time.time() - t0
     rank = int(os.environ.get("RANK", 0))
     if rank == 0:                                                                   # CLI.py:440-465
         os.makedirs(args.save_path, exist_ok=True)
-        from safetensors.torch import save_file
-        out = os.path.join(args.save_path, "generated_latents_0.safetensors")
-        save_file({"latents": sample.float().cpu().contiguous()}, out)
-        print(f"{args.num_inference_steps} steps in {dt:.1f} s ({args.num_inference_steps / dt:.3f} steps/s, TeaCache "
-              f"{'on' if args.enable_teacache else 'off'}); latents -> {out}")
+        index = len([p for p in os.listdir(args.save_path) if p.startswith("generated_video_")])
+        msg = f"{args.num_inference_steps} steps in {dt:.1f} s total (TeaCache {'on' if args.enable_teacache else 'off'})"
+        if decode:
+            from versecrafter_amd.utils.video_io import save_video
+            out = save_video(sample, os.path.join(args.save_path, f"generated_video_{index}.mp4"), fps=args.fps)
+            print(args.prompt)
+            print(f"{msg}; video -> {out}")
+        if not decode or args.output_latents:
+            from safetensors.torch import save_file
+            out = os.path.join(args.save_path, f"generated_latents_{index if decode else 0}.safetensors")
+            save_file({"latents": latents_box["latents"].float().cpu().contiguous()}, out)
+            print(f"{msg}; latents -> {out}")
 
 
 if __name__ == "__main__":

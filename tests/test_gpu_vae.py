@@ -94,3 +94,45 @@ def test_production_width_small_clip_vs_oracle():
     print(f"production width: encode rel L2 {e1:.4g}, decode rel L2 {e2:.4g}")
     assert got.shape == (1, 16, 2, 8, 8) and dec.shape == (1, 3, 5, 64, 64)
     assert e1 < 3e-2 and e2 < 3e-2
+
+
+def test_cli_full_flow_with_vae_and_frame_dumps(tmp_path):
+    """inference/versecrafter_inference.py as the reference runs it (CLI.py:187-465), on tiny random models: control maps and
+    mask read from frame dumps next to the (absent) .mp4 names, first frame from a .png, VAE-encoded on the engine, denoised,
+    VAE-decoded, written as a video (frame dump: the image has no codec)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from PIL import Image
+    from safetensors.torch import save_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    maps = tmp_path / "rendering_4D_maps"
+    maps.mkdir()
+    rs = np.random.RandomState(0)
+    F_, H, W = 9, 64, 96
+    for name in ("background_RGB", "background_depth", "3D_gaussian_RGB", "3D_gaussian_depth"):
+        np.save(maps / f"{name}.npy", rs.randint(0, 255, (F_, H, W, 3), dtype=np.uint8))
+    np.save(maps / "merged_mask.npy", (rs.rand(F_, H, W) < 0.5).astype(np.uint8) * 255)
+    Image.fromarray(rs.randint(0, 255, (H, W, 3), dtype=np.uint8)).save(tmp_path / "0001.png")
+    cfg = V.Config(dim=32, z_dim=16)
+    save_file({k: v.bfloat16() for k, v in V.random_weights(cfg, 3).items()}, str(tmp_path / "vae.safetensors"))
+    g = torch.Generator().manual_seed(0)
+    save_file({"prompt_embeds": torch.randn(33, 4096, generator=g).bfloat16(),
+               "negative_prompt_embeds": torch.randn(20, 4096, generator=g).bfloat16()}, str(tmp_path / "embeds.safetensors"))
+    out_dir = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(root, "inference", "versecrafter_inference.py"), "--rendering_maps_path", str(maps),
+           "--prompt", "a car drives", "--input_image_path", str(tmp_path / "0001.png"), "--ulysses_degree", "1", "--ring_degree", "1",
+           "--num_inference_steps", "4", "--sample_size", f"{H},{W}", "--video_length", str(F_), "--save_path", str(out_dir),
+           "--synthetic_model", "tiny", "--num_skip_start_steps", "2", "--vae_path", str(tmp_path / "vae.safetensors"),
+           "--vae_kwargs", json.dumps({"dim": 32}), "--prompt_embeds_path", str(tmp_path / "embeds.safetensors"), "--output_latents", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    frames = np.load(out_dir / "generated_video_0.npy") if (out_dir / "generated_video_0.npy").exists() else None
+    assert frames is not None or (out_dir / "generated_video_0.mp4").exists(), os.listdir(out_dir)
+    if frames is not None:
+        assert frames.shape == (F_, H, W, 3) and frames.dtype == np.uint8 and frames.std() > 0
+    from safetensors.torch import load_file
+    lat = load_file(str(out_dir / "generated_latents_0.safetensors"))["latents"]
+    assert lat.shape == (1, 16, 3, H // 8, W // 8) and torch.isfinite(lat).all()

@@ -209,3 +209,30 @@ def test_bench_flop_accounting_matches_survey_8d():
     assert 0.015 * f < sk < 0.025 * f
     assert b.skipped_flops(5120, 40, 20, 32760, 2, (512, 512)) < sk          # nothing to fold when the prompts are full
     assert set(b.WORKLOADS) >= {"wan14b-81f-480x832", "wan14b-49f-480x832", "wan14b-81f-720x1280", "wan1.3b-9f-320x512", "tiny"}
+
+
+def test_video_io_frame_dumps_roundtrip(tmp_path):
+    """utils/video_io.py: control maps from frame dumps next to the .mp4 name (the image has no codec), resize to sample_size,
+    cut to video_length; grayscale dumps become 3 channels; the writer falls back to a uint8 frame dump."""
+    import numpy as np
+    from PIL import Image
+    from versecrafter_amd.utils.video_io import read_image, read_video, save_video
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 255, (7, 16, 24, 3), dtype=np.uint8)
+    np.save(tmp_path / "background_RGB.npy", frames)
+    v = read_video(str(tmp_path / "background_RGB.mp4"), 5, (16, 24))
+    assert v.shape == (1, 3, 5, 16, 24) and v.dtype == torch.float32
+    assert torch.equal((v[0, :, 2] * 255).round().to(torch.uint8), torch.from_numpy(frames[2]).permute(2, 0, 1))
+    assert read_video(str(tmp_path / "background_RGB.mp4"), 5, (32, 48)).shape == (1, 3, 5, 32, 48)
+    np.savez(tmp_path / "merged_mask.npz", frames=frames[..., 0])
+    m = read_video(str(tmp_path / "merged_mask.mp4"), 81, (16, 24))
+    assert m.shape == (1, 3, 7, 16, 24) and torch.equal(m[:, 0], m[:, 1])
+    with pytest.raises(FileNotFoundError):
+        read_video(str(tmp_path / "nope.mp4"), 5, (16, 24))
+    Image.fromarray(frames[0]).save(tmp_path / "0001.png")
+    im = read_image(str(tmp_path / "0001.png"), (16, 24))
+    assert im.shape == (1, 3, 1, 16, 24) and torch.equal((im[0, :, 0] * 255).round().to(torch.uint8), torch.from_numpy(frames[0]).permute(2, 0, 1))
+    out = save_video(v, str(tmp_path / "o" / "generated_video_0.mp4"), fps=16)
+    assert os.path.isfile(out)
+    if out.endswith(".npy"):
+        assert np.array_equal(np.load(out), frames[:5])

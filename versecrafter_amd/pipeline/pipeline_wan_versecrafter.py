@@ -4,10 +4,10 @@
 Same constructor (tokenizer, text_encoder, vae, transformer, scheduler) and __call__ signature.  The
 denoise loop (PIPE.py:871-925) is restated in `denoise_step`: CFG batch order [uncond, cond], t.expand(B),
 transformer call, `uncond + g (cond - uncond)`, scheduler.step.  The per-video stages on either side of the
-loop (T5 prompt encoding, VAE encode of the control maps, VAE decode) belong to third-party modules that are
-out of this build's scope: they are used through the same attribute contract when
-the caller provides them, and can be bypassed with `prompt_embeds=` / `negative_prompt_embeds=`,
-`geoada_latents=` and `output_type="latent"`.
+loop (T5 prompt encoding, VAE encode of the control maps, VAE decode) are used through the reference's attribute contract
+(`text_encoder(ids, attention_mask=mask)[0]`, `vae.encode(f)[0].mode()`, `vae.decode(z).sample`): this package's HIP mirrors
+(models.WanT5EncoderModel, models.AutoencoderKLWan) or any object with that surface.  They can be bypassed with
+`prompt_embeds=` / `negative_prompt_embeds=`, `geoada_latents=` and `output_type="latent"`.
 """
 import math
 from dataclasses import dataclass
@@ -96,8 +96,8 @@ class WanVerseCrafterPipeline:
         """PIPE.py:284-363.  Returns two lists of [len_i, text_dim] tensors."""
         def enc(p):
             if self.tokenizer is None or self.text_encoder is None:
-                raise RuntimeError("no tokenizer / text_encoder: pass prompt_embeds and negative_prompt_embeds "
-                                   "(the umT5 encoder is outside this build's scope)")
+                raise RuntimeError("no tokenizer / text_encoder: construct the pipeline with them "
+                                   "(models.WanT5EncoderModel) or pass prompt_embeds and negative_prompt_embeds")
             p = [p] if isinstance(p, str) else p
             ti = self.tokenizer(p, padding="max_length", max_length=max_sequence_length, truncation=True,
                                 add_special_tokens=True, return_tensors="pt")
@@ -115,8 +115,10 @@ class WanVerseCrafterPipeline:
     def geoada_encode_multi_frames(self, multi_frames):
         """PIPE.py:397-438 (ref_images=None): VAE-encode each control video, concat per sample on channels."""
         if self.vae is None:
-            raise RuntimeError("no VAE: pass geoada_latents (the Wan VAE is outside this build's scope)")
+            raise RuntimeError("no VAE: construct the pipeline with vae=models.AutoencoderKLWan(...) or pass geoada_latents")
         enc = [self.vae.encode(f)[0].mode() for f in multi_frames]
+        if hasattr(self.vae, "release_workspace"):
+            self.vae.release_workspace()          # tens of GB of activation buffers: not needed again until the final decode
         return [torch.cat(items, dim=0) for items in zip(*enc)]
 
     def prepare_latents(self, batch_size, channels, shape_thw, dtype, device, generator, latents=None):
@@ -235,4 +237,6 @@ class WanVerseCrafterPipeline:
                 raise RuntimeError("no VAE to decode with: use output_type='latent'")
             frames = self.vae.decode(latents.to(self.vae.dtype)).sample
             video = (frames / 2 + 0.5).clamp(0, 1).cpu().float()
+            if hasattr(self.vae, "release_workspace"):
+                self.vae.release_workspace()
         return WanPipelineOutput(videos=video)
