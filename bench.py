@@ -328,7 +328,8 @@ def run_rank(args):
             "rccl_ranks": rccl_ranks,
             "transport": ("none (single rank)" if not use_dist else
                           "gloo + host-staged buffers (REHEARSAL of the launch, not a result)" if rehearsal else
-                          "engine-owned RCCL communicators, one per block chain"),
+                          "engine-owned RCCL communicators, one per stream lane" if rccl_ranks else
+                          "torch.distributed RCCL process groups, one per stream lane (engine-owned communicators unavailable)"),
         }
         if prof is not None:
             bd = {}

@@ -186,10 +186,35 @@ class SequenceParallel:
         self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
 
     def attach(self, lib, handle):
-        """vc_sp_init / vc_sp_init_rccl on one engine handle (called by the model when the engine is (re)configured)."""
-        if self.transport == "torch":
-            _lib.check(lib.vc_sp_init(handle, self.world_size, self.rank, self.c_all_to_all, self.c_all_gather, None), handle)
-            return
+        """vc_sp_init / vc_sp_init_rccl on one engine handle (called by the model when the engine is (re)configured).
+        If the engine cannot bring up its own communicators on ANY rank (the ranks agree through the torch group), every rank
+        switches to the torch transport -- still RCCL, through torch.distributed -- and says so on stderr; `transport` tells."""
+        if self.transport == "rccl":
+            err = None
+            try:
+                self._attach_rccl(lib, handle)
+            except Exception as e:                      # library missing, bootstrap refused, ...
+                err = e
+            failed = err is not None
+            if self.world_size > 1:
+                host_side = "gloo" in str(dist.get_backend_config(self.group))
+                flag = torch.tensor([1 if failed else 0], device="cpu" if host_side else "cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                failed = bool(flag.item())
+            if not failed:
+                return
+            if self.world_size == 1 or not _group_has_rccl(self.group):
+                raise err if err is not None else RuntimeError("engine-owned RCCL transport failed on another rank")
+            import sys
+            print(f"[versecrafter_amd] rank {self.rank}: engine-owned RCCL communicators unavailable ({err}); "
+                  "falling back to torch.distributed's RCCL process groups", file=sys.stderr)
+            self.transport = "torch"
+            if len(self._lane_groups) == 1:
+                ranks = [dist.get_global_rank(self.group, i) for i in range(self.world_size)]
+                self._lane_groups.append(dist.new_group(ranks=ranks, backend="nccl"))
+        _lib.check(lib.vc_sp_init(handle, self.world_size, self.rank, self.c_all_to_all, self.c_all_gather, None), handle)
+
+    def _attach_rccl(self, lib, handle):
         n = _lib.VC_RCCL_UNIQUE_ID_BYTES
         ids = C.create_string_buffer(2 * n)
         if self.rank == 0:
