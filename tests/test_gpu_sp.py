@@ -104,13 +104,14 @@ def make_model(weights):
 
 @pytest.mark.parametrize("P,seq_len,cfg_pair,lanes", [
     (2, 72, False, None), (4, 72, False, None), (2, 75, False, None), (2, 72, True, None), (4, 75, True, None),
-    (2, 75, True, "0"), (2, 75, True, "1"), (2, 75, False, "1"), (4, 72, True, "2")])
+    (2, 75, True, "0"), (2, 75, True, "1"), (2, 75, False, "1"), (4, 72, True, "2"), (2, 75, True, "3"), (4, 72, False, "3")])
 def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch):
     """seq_len 75 -> padded to 76 for P=2 (WT.py:195-196): compared against SP(1) run at seq_len 76.
     cfg_pair: both samples carry the same latent / control maps (the sampler's CFG pair): the shared block-0 prefix of the
     engine is active on every rank and in the single-rank reference.
-    lanes: the engine's stream schedule (VC_DUAL_LANE): None = default (B = 2 under sequence parallelism: sample lanes -- one
-    sample per stream and communicator), "0" one stream, "1" chain lanes (GeoAdapter chain on its own stream), "2" sample lanes."""
+    lanes: the engine's stream schedule (VC_DUAL_LANE): None = default, "0" one stream, "1" chain lanes (GeoAdapter chain on its
+    own stream), "2" sample lanes (one sample per stream and communicator), "3" sample pipeline (one compute stream alternating
+    between the samples phase by phase, one exchange stream and communicator per sample)."""
     if lanes is not None:
         monkeypatch.setenv("VC_DUAL_LANE", lanes)
     cfg = O.Config(**TINY)
@@ -156,7 +157,7 @@ def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch)
         assert errs[r] is None, (r, errs[r], sps[r].error)
         # two exchanges per self-attention launch; 4 main + 2 adapter blocks.  Sample lanes: block 0 of both chains runs
         # batched, the other four blocks once per sample
-        assert sps[r].calls == (2 * 2 + 2 * 2 * 4 if lanes in (None, "2") else 2 * 6)
+        assert sps[r].calls == (2 * 2 + 2 * 2 * 4 if lanes in (None, "2", "3") else 2 * 6)
         assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
 
 

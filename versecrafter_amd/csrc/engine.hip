@@ -50,6 +50,8 @@ struct Lane {
     int idx = 0;                    // which communicator / stream slot the lane uses
     int b0 = 0, nb = 0;             // the samples of the batch this lane works on: [b0, b0 + nb)
     hipStream_t s = nullptr;
+    hipStream_t comm = nullptr;     // exchanges run here (ordered against `s` by ev[]); nullptr: on `s` itself
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
 };
 
@@ -101,9 +103,14 @@ struct vc_engine {
     //   2  "sample lanes" (B = 2, the CFG pair): sample 0 on the caller's stream, sample 1 on the engine's -- the two samples
     //      never depend on each other, so both streams are busy for the whole step and each one's exchanges run beside the
     //      other's GEMMs / attention; after block 0 of both chains (kept batched: the shared CFG prefix)
+    //   3  "sample pipeline" (B = 2): ONE compute stream that alternates between the two samples phase by phase (up to the
+    //      q|k|v exchange / attention / the rest), each sample's exchanges on its own exchange stream: an exchange is always
+    //      covered by the other sample's next phase, and kernels never share the GPU (no L2 interference between two lanes)
     int lane_mode = 0;
     bool dual = false;              // lane_mode == 1
     hipStream_t s_adp = nullptr;
+    hipStream_t s_comm[2] = {nullptr, nullptr};      // exchange streams of the sample pipeline (lane_mode 3)
+    hipEvent_t ev_lane[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     hipEvent_t ev_x = nullptr, ev_bp = nullptr;
     std::vector<hipEvent_t> ev_hint, ev_used;
     float *f_sin, *f_h, *f_e, *f_e0;
@@ -268,7 +275,9 @@ int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, fl
 
 // one all-to-all / all-gather of the Ulysses exchange on the chain's own stream: the chain's own RCCL communicator, or the
 // host callbacks when the caller brought its own transport (vc_sp_init)
-int sp_all_to_all(vc_engine* h, const Lane& ln, const void* send, void* recv, int64_t bytes_per_peer, const char* what) {
+int sp_all_to_all(vc_engine* h, const Lane& lane, const void* send, void* recv, int64_t bytes_per_peer, const char* what) {
+    Lane ln = lane;
+    if (lane.comm) ln.s = lane.comm;          // the lane's exchange stream
     if (h->comm[ln.idx]) {
         if (vc_comm_all_to_all(h->comm[ln.idx], send, recv, bytes_per_peer, ln.s) != VC_OK)
             return fail(h, VC_E_HIP, "all_to_all (%s): %s", what, vc_comm_error());
@@ -283,7 +292,9 @@ int sp_all_to_all(vc_engine* h, const Lane& ln, const void* send, void* recv, in
         return fail(h, VC_E_STATE, "all_to_all callback failed (%s)", what);
     return VC_OK;
 }
-int sp_all_gather(vc_engine* h, const Lane& ln, const void* send, void* recv, int64_t bytes) {
+int sp_all_gather(vc_engine* h, const Lane& lane, const void* send, void* recv, int64_t bytes) {
+    Lane ln = lane;
+    if (lane.comm) ln.s = lane.comm;
     if (h->comm[ln.idx]) {
         if (vc_comm_all_gather(h->comm[ln.idx], send, recv, bytes, ln.s) != VC_OK)
             return fail(h, VC_E_HIP, "all_gather: %s", vc_comm_error());
@@ -299,8 +310,35 @@ int sp_all_gather(vc_engine* h, const Lane& ln, const void* send, void* recv, in
     return VC_OK;
 }
 
-// self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into ln.attn
-int self_attention(vc_engine* h, Lane& ln, int B) {
+// hand-over between a lane's compute stream and its exchange stream (no-ops when the exchanges run on the compute stream)
+int to_comm(vc_engine* h, Lane& ln, int k) {
+    if (!ln.comm) return VC_OK;
+    HIPCHK(h, hipEventRecord(ln.ev[k], ln.s));
+    HIPCHK(h, hipStreamWaitEvent(ln.comm, ln.ev[k], 0));
+    return VC_OK;
+}
+int from_comm(vc_engine* h, Lane& ln, int k) {
+    if (!ln.comm) return VC_OK;
+    HIPCHK(h, hipEventRecord(ln.ev[k], ln.comm));
+    HIPCHK(h, hipStreamWaitEvent(ln.s, ln.ev[k], 0));
+    return VC_OK;
+}
+
+// self-attention core on the q|k|v buffer (WT.py:392-400); writes token-major [M, d] into ln.attn.  Three phases so that a
+// schedule can put other work of the same stream between an exchange's start and the first use of its result:
+//   pre  : pack q|k|v into the exchange layout, start the q|k|v all-to-all
+//   mid  : attention (over the full sequence with N/P heads), start the o all-to-all
+//   post : unpack o
+// Without the exchange (one rank): mid is the whole thing.
+int sa_pre(vc_engine* h, Lane& ln, int B) {
+    if (!h->sp_exchange) return VC_OK;
+    const int d = h->cfg.dim, Lloc = h->Lloc, P = h->P;
+    const int64_t blk = (int64_t)B * Lloc * (h->cfg.num_heads / P) * 128;      // elements per (peer, q|k|v) block
+    VCCHK(h, vc_launch_sp_pack_qkv(ln.qkv, ln.send, B * Lloc, d, P, ln.s));
+    { int r = to_comm(h, ln, 0); if (r != VC_OK) return r; }
+    return sp_all_to_all(h, ln, ln.send, ln.recv, 3 * blk * 2, "q/k/v");
+}
+int sa_mid(vc_engine* h, Lane& ln, int B) {
     hipStream_t s = ln.s;
     const int d = h->cfg.dim, N = h->cfg.num_heads, Lloc = h->Lloc, P = h->P;
     VcAttnParams a;
@@ -322,8 +360,7 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
     const int Nl = N / P;
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
     const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
-    VCCHK(h, vc_launch_sp_pack_qkv(ln.qkv, ln.send, B * Lloc, d, P, s));
-    { int r = sp_all_to_all(h, ln, ln.send, ln.recv, 3 * blk * 2, "q/k/v"); if (r != VC_OK) return r; }
+    { int r = from_comm(h, ln, 1); if (r != VC_OK) return r; }
     // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
     const char* r = (const char*)ln.recv;
     a.q = r; a.k = r + blk * 2; a.v = r + 2 * blk * 2;
@@ -336,9 +373,14 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
     a.out = ln.send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
     VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
-    { int r = sp_all_to_all(h, ln, ln.send, ln.recv, blk * 2, "o"); if (r != VC_OK) return r; }
+    { int r2 = to_comm(h, ln, 2); if (r2 != VC_OK) return r2; }
+    return sp_all_to_all(h, ln, ln.send, ln.recv, blk * 2, "o");
+}
+int sa_post(vc_engine* h, Lane& ln, int B) {
+    if (!h->sp_exchange) return VC_OK;
+    { int r = from_comm(h, ln, 3); if (r != VC_OK) return r; }
     // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
-    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * Lloc, d, P, s));
+    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * h->Lloc, h->cfg.dim, h->P, ln.s));
     return VC_OK;
 }
 
@@ -348,8 +390,11 @@ int self_attention(vc_engine* h, Lane& ln, int B) {
 // when the CFG pair carries the same latent, timestep and control maps, PIPE.py:878-887): the self-attention half -- all of
 // the block up to the first use of the prompt -- is computed for sample 0 only and its rows are copied to the other samples.
 // Bit-identical to computing every sample (every output row is the same sequence of operations on the same numbers).
+// phases: bit 0 = up to the start of the q|k|v exchange, bit 1 = attention (+ start of the o exchange), bit 2 = the rest; a caller
+// that splits a block must run the three in order on the same lane.
+enum { PH_A = 1, PH_B = 2, PH_C = 4, PH_ALL = 7 };
 int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float hint_scale, Lane& ln,
-              hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr, bool shared_sa = false) {
+              hipEvent_t wait_hint = nullptr, hipEvent_t done = nullptr, bool shared_sa = false, int phases = PH_ALL) {
     hipStream_t s = ln.s;
     const int d = h->cfg.dim, f = h->cfg.ffn_dim, B = ln.nb, Lloc = h->Lloc, M = B * Lloc, TL = h->cfg.text_len;
     const int Bs = shared_sa ? 1 : B, Ms = Bs * Lloc;          // batch / rows of the self-attention half
@@ -357,6 +402,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     const float eps = h->cfg.eps;
     const char* mod = (const char*)ln.mod;
     auto modp = [&](int j) { return (const void*)(mod + (int64_t)j * d * 2); };
+    if (phases & PH_A) {
     // e = modulation + e0  (WT.py:588)
     VCCHK(h, vc_launch_modulation(w.modulation, e0, ln.mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
@@ -373,10 +419,11 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
     { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, 3 * d, Ms, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
     { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)ln.qkv + (int64_t)d * 2, 3 * d, Ms, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
-    {
-        int r = self_attention(h, ln, Bs);
-        if (r != VC_OK) return r;
+    { int r = sa_pre(h, ln, Bs); if (r != VC_OK) return r; }
     }
+    if (phases & PH_B) { int r = sa_mid(h, ln, Bs); if (r != VC_OK) return r; }
+    if (!(phases & PH_C)) return VC_OK;
+    { int r = sa_post(h, ln, Bs); if (r != VC_OK) return r; }
     // x = x + o(attn) * e2  (WT.py:404, 595)
     {
         VcGemmParams g = gemm(ln.attn, d, w.sa_o_w, w.sa_o_b, xs, d, Ms, d, d, VC_EPI_BIAS_GATE_RESID);
@@ -512,8 +559,12 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     const size_t na = h->geoada_layers.size();
     h->ev_hint.resize(na); h->ev_used.resize(na);
     bool ok = hipStreamCreateWithFlags(&h->s_adp, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->s_comm[0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->s_comm[1], hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_bp, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; ok && l < 2; ++l)
+        for (int k = 0; ok && k < 4; ++k) ok = hipEventCreateWithFlags(&h->ev_lane[l][k], hipEventDisableTiming) == hipSuccess;
     for (size_t i = 0; ok && i < na; ++i)
         ok = hipEventCreateWithFlags(&h->ev_hint[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_used[i], hipEventDisableTiming) == hipSuccess;
@@ -525,6 +576,10 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
 void vc_destroy(vc_engine* h) {
     if (!h) return;
     if (h->s_adp) { (void)hipStreamSynchronize(h->s_adp); (void)hipStreamDestroy(h->s_adp); }
+    for (int l = 0; l < 2; ++l) {
+        if (h->s_comm[l]) { (void)hipStreamSynchronize(h->s_comm[l]); (void)hipStreamDestroy(h->s_comm[l]); }
+        for (int k = 0; k < 4; ++k) if (h->ev_lane[l][k]) (void)hipEventDestroy(h->ev_lane[l][k]);
+    }
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
     if (h->ev_bp) (void)hipEventDestroy(h->ev_bp);
     for (auto e : h->ev_hint) if (e) (void)hipEventDestroy(e);
@@ -669,7 +724,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         // VC_DUAL_LANE = 0 / 1 / 2 forces a mode (tests, what-if timing)
         const char* dl = getenv("VC_DUAL_LANE");
         h->lane_mode = dl ? atoi(dl) : (h->sp_exchange ? (B == 2 ? 2 : 1) : 0);
-        if (h->lane_mode < 0 || h->lane_mode > 2 || (h->lane_mode == 2 && B != 2)) h->lane_mode = h->sp_exchange ? 1 : 0;
+        if (h->lane_mode < 0 || h->lane_mode > 3 || (h->lane_mode >= 2 && B != 2)) h->lane_mode = h->sp_exchange ? 1 : 0;
         h->dual = h->lane_mode == 1;
     }
     const int nlanes = h->dual ? 2 : 1;
@@ -831,8 +886,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             VCCHK(h, p_gemm(h, g, la.s));
             return VC_OK;
         };
-        if (h->lane_mode == 2) {
-            // ---- sample lanes (B = 2) ----
+        if (h->lane_mode >= 2) {
+            // ---- sample lanes / sample pipeline (B = 2) ----
             // c = before_proj(c0) + x, then block 0 of both chains, batched on the caller's stream: the CFG pair enters them
             // with identical rows, so their self-attention half is computed once (shared0)
             {
@@ -850,29 +905,50 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             Lane SL[2];
             for (int b = 0; b < 2; ++b) {
                 Lane& v = SL[b];
-                v.idx = b; v.b0 = b; v.nb = 1; v.s = b == 0 ? s : h->s_adp;
+                v.idx = b; v.b0 = b; v.nb = 1; v.s = (b == 0 || h->lane_mode == 3) ? s : h->s_adp;
+                if (h->lane_mode == 3) {
+                    v.comm = h->s_comm[b];
+                    for (int k = 0; k < 4; ++k) v.ev[k] = h->ev_lane[b][k];
+                }
                 const int64_t rows = (int64_t)b * Lloc;
                 v.tb = (char*)L0.tb + rows * d * 2; v.qkv = (char*)L0.qkv + rows * 3 * d * 2;
                 v.attn = (char*)L0.attn + rows * d * 2; v.hb = (char*)L0.hb + rows * c.ffn_dim * 2;
                 v.mod = (char*)L0.mod + (int64_t)b * 6 * d * 2;
                 v.send = (char*)L0.send + rows * 3 * d * 2; v.recv = (char*)L0.recv + rows * 3 * d * 2;
             }
-            HIPCHK(h, hipEventRecord(h->ev_x, s));
-            HIPCHK(h, hipStreamWaitEvent(h->s_adp, h->ev_x, 0));
+            if (h->lane_mode == 2) {
+                HIPCHK(h, hipEventRecord(h->ev_x, s));
+                HIPCHK(h, hipStreamWaitEvent(h->s_adp, h->ev_x, 0));
+            }
+            // one block of either chain for both samples.  Sample lanes: whole block per sample (the streams interleave them);
+            // sample pipeline: phase by phase, alternating between the samples on the one compute stream
+            auto both = [&](const BlockW& w, bool adapter, int n_or_hint) -> int {
+                const int nph = h->lane_mode == 3 ? 3 : 1;
+                for (int ph = 0; ph < nph; ++ph)
+                    for (int b = 0; b < 2; ++b) {
+                        const int64_t ro = (int64_t)b * Lloc * d * 2;
+                        const int phases = nph == 1 ? PH_ALL : (1 << ph);
+                        char* rows = (char*)(adapter ? h->c : h->x) + ro;
+                        const void* hp = (!adapter && n_or_hint >= 0) ? (char*)h->hint[0] + ro : nullptr;
+                        int r = run_block(h, w, rows, hp, adapter ? 0.f : geoada_context_scale, SL[b], nullptr, nullptr, false, phases);
+                        if (r != VC_OK) return r;
+                        if (adapter && (phases & PH_C)) {       // hint_n = after_proj(c)
+                            VcGemmParams g = gemm(rows, d, w.after_w, w.after_b, (char*)h->hint[0] + ro, d, Lloc, d, d);
+                            VCCHK(h, p_gemm(h, g, SL[b].s));
+                        }
+                    }
+                return VC_OK;
+            };
             for (int i = 1; i < c.num_layers; ++i) {
                 const int hn = h->layer_to_hint[i];
                 if (hn >= 0)
-                    for (; next_adapter <= hn; ++next_adapter)
-                        for (int b = 0; b < 2; ++b) { int r = adapter_block(next_adapter, SL[b], 1, false); if (r != VC_OK) return r; }
-                for (int b = 0; b < 2; ++b) {
-                    const int64_t ro = (int64_t)b * Lloc * d * 2;
-                    int r = run_block(h, h->blocks[i], (char*)h->x + ro, hn >= 0 ? (char*)h->hint[0] + ro : nullptr,
-                                      geoada_context_scale, SL[b]);
-                    if (r != VC_OK) return r;
-                }
+                    for (; next_adapter <= hn; ++next_adapter) { int r = both(h->gblocks[next_adapter], true, next_adapter); if (r != VC_OK) return r; }
+                { int r = both(h->blocks[i], false, hn); if (r != VC_OK) return r; }
             }
-            HIPCHK(h, hipEventRecord(h->ev_bp, h->s_adp));               // join
-            HIPCHK(h, hipStreamWaitEvent(s, h->ev_bp, 0));
+            if (h->lane_mode == 2) {
+                HIPCHK(h, hipEventRecord(h->ev_bp, h->s_adp));           // join
+                HIPCHK(h, hipStreamWaitEvent(s, h->ev_bp, 0));
+            }
         } else if (!h->dual) {
             // c = before_proj(c0) + x   (VC.py:113-114)
             {
@@ -953,8 +1029,15 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     }
     const void* y = h->ybuf;
     if (h->sp_exchange) {                                    // VC.py:432-433
-        int r = sp_all_gather(h, L0, h->ybuf, h->yfull, (int64_t)M * c.out_dim * 4 * 2);
+        Lane G = L0;
+        if (h->lane_mode == 3) {                             // communicator 0 lives on sample 0's exchange stream in this schedule
+            G.comm = h->s_comm[0];
+            for (int k = 0; k < 4; ++k) G.ev[k] = h->ev_lane[0][k];
+        }
+        { int r = to_comm(h, G, 0); if (r != VC_OK) return r; }
+        int r = sp_all_gather(h, G, h->ybuf, h->yfull, (int64_t)M * c.out_dim * 4 * 2);
         if (r != VC_OK) return r;
+        { int r2 = from_comm(h, G, 1); if (r2 != VC_OK) return r2; }
         y = h->yfull;
     }
     VCCHK(h, vc_launch_unpatchify(y, out, B, c.out_dim, h->T, h->H2, h->W2, Lloc, s));
