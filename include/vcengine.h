@@ -175,6 +175,11 @@ int vc_op_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batc
 int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, float eps, const void* table,
                        const int32_t* grid5, void* stream);
 
+/* Self-attention front (WT.py:385-392) in one pass over qkv [rows][3 dim]: WanRMSNorm + rope_apply of q and k, in place
+ * (send == NULL), or q, k (normed, rotated) and v written into the Ulysses exchange layout send[P][3][rows][dim / P]. */
+int vc_op_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const void* table,
+                    const int32_t* grid5, void* send, int P, void* stream);
+
 /* Control-map front-end of one sample (PIPE.py:440-488, geoada_encode_masks + geoada_latent, ref_images = None):
  * out [128,T,h,w] bf16 = concat( z [64,T,h,w] bf16 ,  nearest-exact frame resize of the 8x8 pixel-unshuffle of
  * mask[0] [F,H,W] (bf16, or fp32 when mask_is_f32) ).  T = (F+3)/4, h = 2*(H/16) = H/8, w = W/8. */

@@ -340,6 +340,27 @@ def test_rmsnorm_rope(ops, dim, heads):
                       atol=4e-3, what="rmsnorm")
 
 
+@pytest.mark.parametrize("dim,P", [(256, 1), (512, 2), (1536, 3), (5120, 8)])
+def test_qkv_front_equals_separate_norm_rope_and_pack_bitwise(ops, dim, P):
+    """The one-pass self-attention front (RMSNorm + RoPE of q and k, optionally packed with v into the Ulysses exchange layout
+    [P][3][rows][dim/P]) against the separate kernels it replaces: rmsnorm_rope on q, on k, then the layout contract of
+    versecrafter_amd.dist.pack_qkv -- bit for bit, incl. a sequence-parallel token offset and padded (un-rotated) rows."""
+    from versecrafter_amd.dist import pack_qkv
+    rs = np.random.RandomState(dim + P)
+    B, grid, Lr, off = 2, (3, 4, 6), 44, 36                   # rows 36..79 of an 80-row padded sequence: 36 lattice tokens + 8 pads
+    qkv = dev(bf(rs_randn(rs, B * Lr, 3 * dim, scale=1.5)))
+    wq, wk = dev(bf(1 + 0.1 * rs_randn(rs, dim))), dev(bf(1 + 0.1 * rs_randn(rs, dim)))
+    tab = ops.rope_table_device(O.rope_table(128), "cuda")
+    want = qkv.clone()
+    ops.rmsnorm_rope_(want[:, :dim], wq, 1e-6, tab, grid, token_offset=off, rows_per_batch=Lr)
+    ops.rmsnorm_rope_(want[:, dim:2 * dim], wk, 1e-6, tab, grid, token_offset=off, rows_per_batch=Lr)
+    got = ops.qkv_front(qkv.clone(), wq, wk, tab, grid, token_offset=off, rows_per_batch=Lr)
+    assert torch.equal(got, want)
+    send = ops.qkv_front(qkv.clone(), wq, wk, tab, grid, token_offset=off, rows_per_batch=Lr, P=P, pack=True)
+    ref = pack_qkv(want.view(B, Lr, 3, dim // 128, 128), P)    # [P, 3, B, Lr, N/P, 128]
+    assert torch.equal(send.view(-1), ref.reshape(-1))
+
+
 # ------------------------------------------------------------------------ full-size (cfg-3) property tests
 # At BASELINE.json's sizes the CPU oracle is out of reach (44 TFLOP per attention call), so the kernels are checked through
 # size-independent properties of the maths they implement.

@@ -75,6 +75,7 @@ SYMBOLS = {
                                       C.POINTER(_L), C.POINTER(C.c_int32), _F, _P]),
     "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
+    "vc_op_qkv_front": (_I, [_P, _I, _I, _P, _P, _F, _P, C.POINTER(C.c_int32), _P, _I, _P]),
     "vc_op_geoada_context": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vc_op_unipc_update": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, C.POINTER(_F), _I, _P]),
     "vc_vae_create": (_I, [C.POINTER(vc_vae_config), C.POINTER(_P)]),

@@ -332,9 +332,9 @@ int from_comm(vc_engine* h, Lane& ln, int k) {
 // Without the exchange (one rank): mid is the whole thing.
 int sa_pre(vc_engine* h, Lane& ln, int B) {
     if (!h->sp_exchange) return VC_OK;
-    const int d = h->cfg.dim, Lloc = h->Lloc, P = h->P;
+    const int Lloc = h->Lloc, P = h->P;
     const int64_t blk = (int64_t)B * Lloc * (h->cfg.num_heads / P) * 128;      // elements per (peer, q|k|v) block
-    VCCHK(h, vc_launch_sp_pack_qkv(ln.qkv, ln.send, B * Lloc, d, P, ln.s));
+    // (q|k|v are already in the exchange layout: written there by the norm + RoPE pass)
     { int r = to_comm(h, ln, 0); if (r != VC_OK) return r; }
     return sp_all_to_all(h, ln, ln.send, ln.recv, 3 * blk * 2, "q/k/v");
 }
@@ -415,10 +415,13 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         g.Wg[1] = w.sa_v_w; g.biasg[1] = w.sa_v_b; g.Cg[1] = (char*)ln.qkv + (int64_t)2 * d * 2;
         VCCHK(h, p_gemm(h, g, s));
     }
-    // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392)
+    // full-dim RMSNorm + RoPE on q and k  (WT.py:385-386, 392) in one pass; under sequence parallelism the same pass writes q, k
+    // and v straight into the exchange layout (no separate pack)
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope(ln.qkv, 3 * d, Ms, d, w.sa_nq, eps, h->rope_dev, &rg, s)); }
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_rmsnorm_rope((char*)ln.qkv + (int64_t)d * 2, 3 * d, Ms, d, w.sa_nk, eps, h->rope_dev, &rg, s)); }
+    {
+        ProfScope ps(h, s, VC_PROF_ROW, 0, (h->sp_exchange ? 12.0 : 8.0) * Ms * d);
+        VCCHK(h, vc_launch_qkv_front(ln.qkv, Ms, d, w.sa_nq, w.sa_nk, eps, h->rope_dev, &rg, h->sp_exchange ? ln.send : nullptr, h->P, s));
+    }
     { int r = sa_pre(h, ln, Bs); if (r != VC_OK) return r; }
     }
     if (phases & PH_B) { int r = sa_mid(h, ln, Bs); if (r != VC_OK) return r; }
@@ -723,7 +726,11 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     {   // default: two streams only under sequence parallelism (sample lanes for the CFG pair, chain lanes otherwise);
         // VC_DUAL_LANE = 0 / 1 / 2 forces a mode (tests, what-if timing)
         const char* dl = getenv("VC_DUAL_LANE");
-        h->lane_mode = dl ? atoi(dl) : (h->sp_exchange ? (B == 2 ? 2 : 1) : 0);
+        // the CFG pair: sample pipeline while one sample's d x d GEMM still fills >= 4 rounds of the 256 CUs (P <= 2 at cfg-3:
+        // measured 2201 vs 2466 ms per rank), sample lanes below that (two streams interleave the short kernels' tails: P = 8:
+        // 546 vs 645 ms; P = 4: equal) -- tools/sim_sp_rank.py, profiles/r02_sim_sp_rank.jsonl
+        const int64_t tiles_1 = (int64_t)((Lloc + 255) / 256) * (d / 256 > 0 ? d / 256 : 1);
+        h->lane_mode = dl ? atoi(dl) : (h->sp_exchange ? (B == 2 ? (tiles_1 >= 1024 ? 3 : 2) : 1) : 0);
         if (h->lane_mode < 0 || h->lane_mode > 3 || (h->lane_mode >= 2 && B != 2)) h->lane_mode = h->sp_exchange ? 1 : 0;
         h->dual = h->lane_mode == 1;
     }
@@ -1138,6 +1145,13 @@ int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, fl
     }
     return vc_launch_rmsnorm_rope(x, ld, rows, dim, w, eps, (const float2*)table, table ? &g : nullptr,
                                   (hipStream_t)stream);
+}
+
+int vc_op_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const void* table,
+                    const int32_t* grid5, void* send, int P, void* stream) {
+    if (!grid5) return VC_E_INVALID;
+    VcRopeGrid g{grid5[0], grid5[1], grid5[2], grid5[3], grid5[4]};
+    return vc_launch_qkv_front(qkv, rows, dim, wq, wk, eps, (const float2*)table, &g, send, P, (hipStream_t)stream);
 }
 
 int vc_op_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F, int H,

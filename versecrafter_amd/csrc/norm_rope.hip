@@ -150,7 +150,110 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
     }
 }
 
+// Self-attention front (WT.py:385-392) in ONE pass over the q|k|v buffer [rows][3 dim]: blockIdx.y = 0 / 1: full-dim RMSNorm + RoPE
+// of q / k (arithmetic of rmsnorm_rope_kernel, bit for bit), blockIdx.y = 2: v.  Written in place (send == nullptr; v is then
+// not launched) or straight into the Ulysses exchange layout send[P_dst][3][rows][dim / P] -- which makes the separate pack pass
+// (and its second read + write of q|k|v) disappear.
+template <int MAXC>
+__global__ __launch_bounds__(256) void qkv_front_kernel(bf16_t* __restrict__ qkv, int rows, int dim, const bf16_t* __restrict__ wq,
+                                                        const bf16_t* __restrict__ wk, float eps, const float2* __restrict__ table,
+                                                        VcRopeGrid grid, bf16_t* __restrict__ send, int P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
+    const int which = blockIdx.y;
+    if (row >= rows) return;
+    bf16_t* xr = qkv + (int64_t)row * 3 * dim + (int64_t)which * dim;
+    const int hd = dim / P;
+    auto out_ptr = [&](int idx) -> bf16_t* {
+        if (!send) return xr + idx;
+        const int peer = idx / hd;
+        return send + (((int64_t)peer * 3 + which) * rows + row) * hd + (idx - peer * hd);
+    };
+    uint4 raw[MAXC];
+    if (which == 2) {                                  // v: move only
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int idx = c * 512 + lane * 8;
+            if (idx < dim) *(uint4*)out_ptr(idx) = *(const uint4*)(xr + idx);
+        }
+        return;
+    }
+    const bf16_t* w = which == 0 ? wq : wk;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            raw[c] = *(const uint4*)(xr + idx);
+            float f[8];
+            unpack8(raw[c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    const float inv = round_bf16(rsqrtf(wave_sum(ss) / (float)dim + eps));   // rsqrt(...).to(bf16), WT.py:323
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) asm volatile("" : "+v"(raw[c].x), "+v"(raw[c].y), "+v"(raw[c].z), "+v"(raw[c].w));
+    float cs[4], sn[4];
+    bool rot = false;
+    {
+        const int tok = grid.token_offset + (grid.rows_per_batch > 0 ? row % grid.rows_per_batch : row);
+        if (tok < grid.F * grid.H * grid.W) {
+            rot = true;
+            const int hw = grid.H * grid.W;
+            const int pf = tok / hw, ph = (tok / grid.W) % grid.H, pw = tok % grid.W;
+            const int j0 = (lane & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                const int pos = j < 22 ? pf : (j < 43 ? ph : pw);
+                const float2 t = table[pos * 64 + j];
+                cs[e] = t.x;
+                sn[e] = t.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int idx = c * 512 + lane * 8;
+        if (idx < dim) {
+            float f[8], ww[8];
+            unpack8(raw[c], f);
+            unpack8(*(const uint4*)(w + idx), ww);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = round_bf16(round_bf16(f[e] * inv) * ww[e]);
+            if (rot) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = f[2 * e], bq = f[2 * e + 1];
+                    f[2 * e] = a * cs[e] - bq * sn[e];
+                    f[2 * e + 1] = a * sn[e] + bq * cs[e];
+                }
+            }
+            *(uint4*)out_ptr(idx) = pack8(f);
+        }
+    }
+}
+
 }  // namespace
+
+int vc_launch_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const float2* rope_table,
+                        const VcRopeGrid* grid, void* send, int P, hipStream_t stream) {
+    if (!qkv || !wq || !wk || !rope_table || !grid || rows <= 0 || dim <= 0 || P <= 0) return VC_E_INVALID;
+    if (dim % 128 || dim > 8192 || dim % P || (dim / P) % 128) return VC_E_UNSUPPORTED;
+    const VcRopeGrid g = *grid;
+    if (g.F > 1024 || g.H > 1024 || g.W > 1024 || g.F <= 0 || g.H <= 0 || g.W <= 0) return VC_E_INVALID;
+    const dim3 gr((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, send ? 3 : 2), block(256);
+#define QF_LAUNCH(MC)                                                                                               \
+    hipLaunchKernelGGL(qkv_front_kernel<MC>, gr, block, 0, stream, (bf16_t*)qkv, rows, dim, (const bf16_t*)wq,      \
+                       (const bf16_t*)wk, eps, rope_table, g, (bf16_t*)send, P)
+    if (dim <= 512) QF_LAUNCH(1);
+    else if (dim <= 2048) QF_LAUNCH(4);
+    else if (dim <= 5120) QF_LAUNCH(10);
+    else QF_LAUNCH(16);
+#undef QF_LAUNCH
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
 
 int vc_launch_layernorm(const void* x, void* y, int rows, int dim, int rows_per_batch, float eps, int mode,
                         const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream) {

@@ -73,6 +73,11 @@ int vc_launch_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w
                            const float2* rope_table /*[1024][64] (cos,sin)*/, const VcRopeGrid* grid,
                            hipStream_t stream);
 
+// self-attention front in one pass over qkv [rows][3 dim]: RMSNorm + RoPE of q and k (in place when send == nullptr), or q, k
+// (normed, rotated) and v written straight into the Ulysses exchange layout send[P][3][rows][dim / P]
+int vc_launch_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const float2* rope_table,
+                        const VcRopeGrid* grid, void* send, int P, hipStream_t stream);
+
 // ---- small kernels ------------------------------------------------------------------------
 // A[b*Lrows + i, c*4 + p*2 + q] = x[b, c, f, 2h+p, 2w+q] for token tok = tok_offset + i = (f, h, w)
 // (rows with tok >= F*H2*W2 are zero).  Lrows / tok_offset select a rank's sequence chunk (VC.py:366-367).
