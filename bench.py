@@ -6,15 +6,16 @@ Metric (BASELINE.json): denoise-steps/sec, Wan2.1-14B + GeoAdapter, 81 frames x 
 iteration of the reference's sampler loop (pipeline_wan_versecrafter.py:871-925): transformer forward at B=2,
 CFG combine, UniPC scheduler step.  Synthetic inputs and random weights of that architecture; all
 inputs are resident in HBM before the timed region.  For N > 1 the frames x h x w token sequence is sharded
-Ulysses-style over the ranks (one process per GPU, torch.distributed "nccl" = RCCL): total work is fixed, so
-"scaling" is "strong".  Rank 0 prints ONE JSON line.
+Ulysses-style over the ranks, one process per GPU, the exchanges on RCCL communicators the engine owns: total work is
+fixed, so "scaling" is "strong".  `python bench.py --gpus N` without a launcher around it starts its own N ranks (torchrun's
+environment contract) and forwards rank 0's line; under torchrun it runs as a rank.  Rank 0 prints ONE JSON line.
 
 The same line carries
   roofline     : the dominant kernel class of the timed region (HIP events around every launch of the class,
                  on the launch stream) -- algorithmic FLOPs / summed duration vs the dense bf16 MFMA peak;
   breakdown    : the same for every kernel class, plus the whole-step fraction of the MFMA roofline;
   cpu_baseline : the CPU oracle (oracle/wan_oracle.py, fp32 PyTorch) timed on this box's host cores on a bounded
-                 sample (one DiT block at the 14B width on a 1536-token slice) and extrapolated by FLOPs.
+                 sample (one main + one adapter block at the 14B width on a 1536-token slice) and extrapolated by FLOPs.
 """
 import argparse
 import json
@@ -359,9 +360,9 @@ def run_rank(args):
                                "traffic_source": (f"recorded, not live: {traffic_src}" if traffic is not None else None),
                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
             if world > 1:
-                out["roofline"]["note"] = ("sequence-parallel run: the GeoAdapter chain runs on its own stream, so launches of the "
-                                           "two chains overlap and the per-launch durations (hence 'achieved') are lower bounds; "
-                                           "the N=1 line carries the kernel roofline")
+                out["roofline"]["note"] = ("sequence-parallel run: the two samples of the CFG pair are scheduled on separate "
+                                           "streams / interleaved with exchanges, so kernel launches can overlap and the per-launch "
+                                           "durations (hence 'achieved') are lower bounds; the N=1 line carries the kernel roofline")
             out["breakdown"] = bd
         if tea is not None:
             out["teacache_on"] = tea
