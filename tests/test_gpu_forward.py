@@ -561,3 +561,17 @@ def test_fused_sampler_update_vs_unipc_oracle_per_step(n_steps, shift, do_cfg):
     rel_free = float(np.linalg.norm(f64(xb) - x_free) / np.linalg.norm(x_free))
     print(f"unipc n={n_steps} shift={shift}: worst per-step error {worst:.2f} ulp_bf16, free-running rel L2 {rel_free:.3g}")
     assert rel_free < 3e-2
+
+
+def test_time_embedding_vs_oracle(model):
+    """a11 in isolation: sinusoidal_embedding_1d (WT.py:39-49) -> time_embedding -> time_projection (VC.py:347-350), fp32 on
+    the engine (vc_time_embedding) against the oracle on the same bf16-rounded weights; timesteps across the schedule."""
+    cfg = O.Config(**TINY)
+    W = {k: v.bfloat16().float() for k, v in O.random_weights(cfg, 7).items()}
+    t = torch.tensor([999.0, 875.0, 500.0, 31.0, 1.0, 0.0])
+    got = model.time_embedding_e0(t.cuda()).cpu()
+    e, e0 = O.time_embed(W, t, cfg.dim, cfg.freq_dim)
+    assert got.shape == e0.shape == (6, 6, cfg.dim)
+    err = (got - e0).abs().max().item()
+    print(f"time embedding: max abs err {err:.3g} (|e0| max {e0.abs().max():.3g})")
+    assert torch.allclose(got, e0, rtol=1e-4, atol=1e-4 * float(e0.abs().max()))       # fp32 dot products, different summation order
