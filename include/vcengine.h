@@ -230,7 +230,7 @@ void vc_t5_destroy(vc_t5* h);
  *   encoder.conv1, encoder.downsamples.N.{residual.{0,3}.gamma, residual.{2,6}, shortcut, resample.1, time_conv},
  *   encoder.middle.{0,2}.*, encoder.middle.1.{norm.gamma, to_qkv, proj}, encoder.head.{0.gamma, 2}, conv1, conv2, decoder.* ;
  * they are re-packed once (tap-major, channels padded to 64) into library-owned memory at the first encode / decode.
- * The workspace (six buffers of the largest activation: ~70 GB for an 81-frame 480p decode) is allocated at the first call that
+ * The workspace (five buffers of the largest activation: ~60 GB for an 81-frame 480p decode) is allocated at the first call that
  * needs it and kept -- a video takes four encodes and one decode, and allocating tens of GB costs seconds -- until
  * vc_vae_release_workspace or vc_vae_destroy; encode / decode return without a host sync. */
 typedef struct vc_vae_config {

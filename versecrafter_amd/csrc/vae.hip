@@ -965,7 +965,7 @@ int walk_decode(vc_vae* h, Runner& R, const void* z, void* out, int T, int hh, i
     return R.rc;
 }
 
-constexpr int VAE_SLOTS = 6;
+constexpr int VAE_SLOTS = 5;     // most buffers alive at once: 4 (ResidualBlock: x, conv-1 output, its norm, shortcut)
 
 template <class Walk>
 int run_sized(vc_vae* h, hipStream_t s, Walk walk) {
