@@ -204,7 +204,8 @@ def test_collective_callbacks_on_rccl_world1():
             dist.destroy_process_group()
 
 
-def test_engine_owned_rccl_exchange_world1_bitwise():
+@pytest.mark.parametrize("lanes,a2a", [(None, None), ("3", None), ("1", None), ("2", "p2p"), ("3", "p2p")])
+def test_engine_owned_rccl_exchange_world1_bitwise(lanes, a2a, monkeypatch):
     """The product transport (vc_sp_init_rccl: librccl bound with dlopen, two communicators, one per block chain) with a
     1-rank world and VC_SP_FORCE_EXCHANGE: the model takes the whole N > 1 path -- q|k|v pack, ncclAllToAll on the chain's
     stream, segmented attention, ncclAllToAll, head unpack, ncclAllGather, both chains on their own streams -- and must
@@ -220,6 +221,12 @@ def test_engine_owned_rccl_exchange_world1_bitwise():
     ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
     t = torch.tensor([640.0, 640.0]).cuda()
     ref = make_model(W)(x, t, geo, ctx, 72)
+    # lanes: the stream schedule the production sizes pick (sample pipeline "3" at P <= 2 of cfg-3, sample lanes "2" above, chain
+    # lanes "1" for B != 2); a2a "p2p": the all-to-all as grouped ncclSend / ncclRecv instead of ncclAllToAll
+    if lanes is not None:
+        monkeypatch.setenv("VC_DUAL_LANE", lanes)
+    if a2a is not None:
+        monkeypatch.setenv("VC_SP_A2A", a2a)
     m = make_model(W)
     sp = SequenceParallel(None, transport="rccl", force_exchange=True)
     assert sp.world_size == 1 and sp.transport == "rccl"
