@@ -135,25 +135,6 @@ __global__ void pad_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restri
     }
 }
 
-__global__ void copy_strided_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols8,
-                                    int64_t src_ld, int64_t dst_ld) {
-    const int64_t n = (int64_t)rows * cols8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / cols8), c = (int)(i % cols8);
-        *(uint4*)(dst + (int64_t)r * dst_ld + c * 8) = *(const uint4*)(src + (int64_t)r * src_ld + c * 8);
-    }
-}
-
-// Ulysses pack: qkv [M, 3*d] -> send [P][3][M][hd], hd = d / P   (16-byte chunks)
-__global__ void sp_pack_qkv_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ send, int M, int d8, int hd8) {
-    const int64_t n = (int64_t)M * 3 * d8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % (3 * d8)), row = (int)(i / (3 * d8));
-        const int w = col / d8, within = col - w * d8;
-        const int dst = within / hd8, c = within - dst * hd8;
-        ((uint4*)send)[((int64_t)(dst * 3 + w) * M + row) * hd8 + c] = ((const uint4*)qkv)[i];
-    }
-}
 // Ulysses unpack: recv [P][M][hd] -> attn [M, d]
 __global__ void sp_unpack_o_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ attn, int M, int d8, int hd8) {
     const int64_t n = (int64_t)M * d8;
@@ -307,14 +288,6 @@ int vc_launch_pad_rows(const void* src, void* dst, int len, int total, int dim, 
     return ok();
 }
 
-int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
-                           hipStream_t st) {
-    if (!src || !dst || rows <= 0 || cols <= 0 || cols % 8 || src_ld % 8 || dst_ld % 8) return VC_E_INVALID;
-    hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((int64_t)rows * cols / 8, 256)), dim3(256), 0, st,
-                       (const bf16_t*)src, (bf16_t*)dst, rows, cols / 8, src_ld, dst_ld);
-    return ok();
-}
-
 // Occupies `st` for `usec` microseconds with one idle wave (what-if timing of an exchange's wire time: tools/sim_sp_rank.py).
 // The wave polls the constant-rate wall clock and sleeps in between; it exits on the deadline or after a fixed number of polls.
 __global__ void delay_kernel(uint64_t ticks) {
@@ -336,13 +309,6 @@ int vc_launch_delay(double usec, hipStream_t st) {
     const uint64_t ticks = (uint64_t)(usec * 1e-3 * khz);
     if (ticks == 0) return VC_OK;
     hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, ticks);
-    return ok();
-}
-
-int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st) {
-    if (!qkv || !send || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
-    hipLaunchKernelGGL(sp_pack_qkv_kernel, dim3(grid_for((int64_t)M * 3 * d / 8, 256)), dim3(256), 0, st,
-                       (const bf16_t*)qkv, (bf16_t*)send, M, d / 8, d / P / 8);
     return ok();
 }
 

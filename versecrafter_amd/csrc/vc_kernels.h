@@ -104,16 +104,12 @@ int vc_launch_unipc_update(const void* noise_uncond, const void* noise_cond, con
                            const float* sc, int flags, hipStream_t st);
 int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F,
                              hipStream_t st);
-// Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py):
-//   pack   qkv [M, 3d]       -> send [P_dst][3][M][d/P]
+// Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py).  q|k|v reach the send layout [P_dst][3][M][d/P] through
+// vc_launch_qkv_front; the return path needs:
 //   unpack recv [P_src][M][d/P] -> attn [M, d]
-int vc_launch_sp_pack_qkv(const void* qkv, void* send, int M, int d, int P, hipStream_t st);
 int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st);
 // one idle wave holds the stream for `usec` microseconds (what-if timing only)
 int vc_launch_delay(double usec, hipStream_t st);
-// generic strided 2-D copy
-int vc_launch_copy_strided(const void* src, void* dst, int rows, int cols, int64_t src_ld, int64_t dst_ld,
-                           hipStream_t st);
 
 // ---- RCCL transport of the Ulysses exchange (sp_rccl.hip); librccl is bound with dlopen at first use ----
 #define VC_RCCL_UNIQUE_ID_BYTES 128
