@@ -41,6 +41,9 @@ namespace {
 #ifndef VC_ATTN_ABLATE
 #define VC_ATTN_ABLATE 0
 #endif
+#ifndef VC_ATTN_QK_INTERLEAVE
+#define VC_ATTN_QK_INTERLEAVE 0
+#endif
 
 constexpr int D = 128;
 constexpr int KT = 64;      // keys per tile
@@ -228,6 +231,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     float m_run = -1e30f, m_new = -1e30f, l_run = 0.f;
 
     auto qk = [&](const char* kbuf, f32x16 (&S)[2]) {
+#if VC_ATTN_QK_INTERLEAVE      // the two 32-key halves alternate: every MFMA depends on the one TWO back, not on its predecessor
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
+            }
+#else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
                 S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
             }
         }
+#endif
     };
     auto mask_tail = [&](f32x16 (&S)[2], int t) {      // keys >= k_len of the (last) tile t
 #pragma unroll
