@@ -242,10 +242,12 @@ class SequenceParallel:
         return t
 
     def _group_for(self, stream):
-        """The engine's two chains call back with two different streams (first seen: deterministic, the same program runs
-        on every rank); chain k uses process group k when there is more than one."""
+        """The engine calls back with one stream per lane (numbered in order of first appearance: deterministic, the same
+        program runs on every rank) -- two under the lane schedules, three under the sample pipeline (the caller's stream for
+        the batched first block and the final gather, then one exchange stream per sample).  Lane k uses process group
+        k mod 2, which keeps the two samples' exchanges on different groups in every schedule."""
         lane = self._lane_of_stream.setdefault(stream, len(self._lane_of_stream))
-        return self._lane_groups[min(lane, len(self._lane_groups) - 1)]
+        return self._lane_groups[lane % len(self._lane_groups)]
 
     @staticmethod
     def _on(stream):
