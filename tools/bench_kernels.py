@@ -86,6 +86,19 @@ def bench_row():
     mod = torch.randn(2, 6, d, device="cuda", generator=g).bfloat16()
     med, mn = timeit(lambda: ops.layernorm_modulate(x, mod[:, 1], mod[:, 0], M // 2))
     print(f"layernorm_modulate [{M},{d}]: median {med:.3f} ms ({4.0 * M * d / med / 1e6:.0f} GB/s)", flush=True)
+    from oracle import wan_oracle as O
+    qkv = torch.randn(M, 3 * d, device="cuda", generator=g).bfloat16()
+    wq, wk = torch.ones(d, device="cuda").bfloat16(), torch.ones(d, device="cuda").bfloat16()
+    tab = ops.rope_table_device(O.rope_table(128), "cuda")
+    grid = (21, 30, 52)
+    med, mn = timeit(lambda: ops.qkv_front(qkv, wq, wk, tab, grid, rows_per_batch=M // 2))
+    print(f"qkv_front in place (q and k of [{M},{3 * d}]): median {med:.3f} ms ({8.0 * M * d / med / 1e6:.0f} GB/s)", flush=True)
+    med, mn = timeit(lambda: (ops.rmsnorm_rope_(qkv[:, :d], wq, 1e-6, tab, grid, rows_per_batch=M // 2),
+                              ops.rmsnorm_rope_(qkv[:, d:2 * d], wk, 1e-6, tab, grid, rows_per_batch=M // 2)))
+    print(f"two rmsnorm_rope launches (same bytes): median {med:.3f} ms ({8.0 * M * d / med / 1e6:.0f} GB/s)", flush=True)
+    Mp = M // 8
+    med, mn = timeit(lambda: ops.qkv_front(qkv[:Mp], wq, wk, tab, grid, rows_per_batch=Mp // 2, P=8, pack=True))
+    print(f"qkv_front packed, P=8 rank share [{Mp},{3 * d}]: median {med:.3f} ms ({12.0 * Mp * d / med / 1e6:.0f} GB/s)", flush=True)
 
 
 if __name__ == "__main__":

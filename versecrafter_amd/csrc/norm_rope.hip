@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
 // of q / k (arithmetic of rmsnorm_rope_kernel, bit for bit), blockIdx.y = 2: v.  Written in place (send == nullptr; v is then
 // not launched) or straight into the Ulysses exchange layout send[P_dst][3][rows][dim / P] -- which makes the separate pack pass
 // (and its second read + write of q|k|v) disappear.
-template <int MAXC>
+template <int MAXC, bool PACK>
 __global__ __launch_bounds__(256) void qkv_front_kernel(bf16_t* __restrict__ qkv, int rows, int dim, const bf16_t* __restrict__ wq,
                                                         const bf16_t* __restrict__ wk, float eps, const float2* __restrict__ table,
                                                         VcRopeGrid grid, bf16_t* __restrict__ send, int P) {
@@ -164,13 +164,16 @@ __global__ __launch_bounds__(256) void qkv_front_kernel(bf16_t* __restrict__ qkv
     if (row >= rows) return;
     bf16_t* xr = qkv + (int64_t)row * 3 * dim + (int64_t)which * dim;
     const int hd = dim / P;
+    const float inv_hd = 1.0f / (float)hd;              // idx / hd for idx < 8192, hd >= 128: exact through the reciprocal
+    bf16_t* srow = PACK ? send + ((int64_t)which * rows + row) * hd : nullptr;
+    const int64_t peer_stride = (int64_t)3 * rows * hd;
     auto out_ptr = [&](int idx) -> bf16_t* {
-        if (!send) return xr + idx;
-        const int peer = idx / hd;
-        return send + (((int64_t)peer * 3 + which) * rows + row) * hd + (idx - peer * hd);
+        if (!PACK) return xr + idx;
+        const int peer = (int)(((float)idx + 0.5f) * inv_hd);
+        return srow + peer * peer_stride + (idx - peer * hd);
     };
     uint4 raw[MAXC];
-    if (which == 2) {                                  // v: move only
+    if (PACK && which == 2) {                          // v: move only
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int idx = c * 512 + lane * 8;
@@ -244,9 +247,13 @@ int vc_launch_qkv_front(void* qkv, int rows, int dim, const void* wq, const void
     const VcRopeGrid g = *grid;
     if (g.F > 1024 || g.H > 1024 || g.W > 1024 || g.F <= 0 || g.H <= 0 || g.W <= 0) return VC_E_INVALID;
     const dim3 gr((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, send ? 3 : 2), block(256);
-#define QF_LAUNCH(MC)                                                                                               \
-    hipLaunchKernelGGL(qkv_front_kernel<MC>, gr, block, 0, stream, (bf16_t*)qkv, rows, dim, (const bf16_t*)wq,      \
-                       (const bf16_t*)wk, eps, rope_table, g, (bf16_t*)send, P)
+#define QF_LAUNCH(MC)                                                                                                    \
+    do {                                                                                                                 \
+        if (send) hipLaunchKernelGGL((qkv_front_kernel<MC, true>), gr, block, 0, stream, (bf16_t*)qkv, rows, dim,        \
+                                     (const bf16_t*)wq, (const bf16_t*)wk, eps, rope_table, g, (bf16_t*)send, P);        \
+        else hipLaunchKernelGGL((qkv_front_kernel<MC, false>), gr, block, 0, stream, (bf16_t*)qkv, rows, dim,            \
+                                (const bf16_t*)wq, (const bf16_t*)wk, eps, rope_table, g, (bf16_t*)send, P);             \
+    } while (0)
     if (dim <= 512) QF_LAUNCH(1);
     else if (dim <= 2048) QF_LAUNCH(4);
     else if (dim <= 5120) QF_LAUNCH(10);
