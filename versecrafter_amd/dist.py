@@ -32,8 +32,9 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int):
     degree = int(ulysses_degree) * int(ring_degree)
     if degree > 1:
         if not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-            dist.init_process_group(backend)
+            # host-side gloo for rendezvous / object broadcast (the ncclUniqueIds of the engine's communicators), torch's
+            # "nccl" (= RCCL) registered for device tensors; the engine's exchanges never go through torch
+            dist.init_process_group("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
         if dist.get_world_size() != degree:
             raise ValueError(f"ulysses_degree*ring_degree = {degree} but world size is {dist.get_world_size()}")
         if int(ring_degree) > 1 and dist.get_rank() == 0:
