@@ -31,10 +31,12 @@ WIDE = dict(dim=1536, ffn_dim=2048, num_heads=12, num_layers=2, text_dim=64, tex
             geoada_in_dim=128, in_dim=16, out_dim=16, freq_dim=256)
 
 
-def _worker(rank, world, port, seq_len, steps, q, wide=False):
+def _worker(rank, world, port, seq_len, steps, q, wide=False, lanes=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")                           # both ranks share cuda:0
+    if lanes is not None:
+        os.environ["VC_DUAL_LANE"] = lanes                      # force a stream schedule (engine.hip: lane_mode)
     import torch.distributed as dist
     from oracle import wan_oracle as O
     from versecrafter_amd import dist as vdist
@@ -76,15 +78,18 @@ def _worker(rank, world, port, seq_len, steps, q, wide=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("seq_len,wide,world", [(72, False, 2), (75, False, 2), (1860, True, 2), (1860, True, 4)])
-def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide, world):
+@pytest.mark.parametrize("seq_len,wide,world,lanes", [(72, False, 2, None), (75, False, 2, None), (1860, True, 2, None),
+                                                      (1860, True, 4, None), (1860, True, 2, "3"), (75, False, 2, "1")])
+def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide, world, lanes):
     """wide: 1.3B width, 1860 tokens -> 930 per rank (not a multiple of the 4-row staging pieces): the ping-pong GEMM
     (M = 1860 >= 1024), the segmented attention's scalar-addressed fast path with pieces straddling the rank boundary, the
-    pack / unpack kernels and both engine lanes, across two (or four: 465 tokens per rank, 3 heads each) processes."""
+    pack / unpack kernels and both engine lanes, across two (or four: 465 tokens per rank, 3 heads each) processes.
+    lanes: None = the default schedule for the shape (sample lanes), "3" the sample pipeline (what cfg-3 picks at P = 2: one
+    compute stream, an exchange stream per sample), "1" chain lanes."""
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, seq_len, 2, q, wide)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, seq_len, 2, q, wide, lanes)) for r in range(world)]
     for p in procs:
         p.start()
     try:
