@@ -41,12 +41,16 @@ def main():
                 print(f"   {k:28s} {v:.4g}")
         g = lambda d, k: d.get(k, float("nan"))
         wc = g(a, "SQ_WAVE_CYCLES")
-        print(f"   -> MFMA pipe busy / SQ busy       : {g(a, 'SQ_VALU_MFMA_BUSY_CYCLES') / g(a, 'SQ_BUSY_CYCLES'):.3f}")
-        print(f"   -> MFMA instructions per VALU inst : {g(a, 'SQ_INSTS_MFMA') / g(a, 'SQ_INSTS_VALU'):.3f}")
-        print(f"   -> waiting (any) / wave cycles     : {g(a, 'SQ_WAIT_INST_ANY') / wc:.3f}")
-        print(f"   -> issuing (any) / wave cycles     : {g(a, 'SQ_ACTIVE_INST_ANY') / wc:.3f}")
-        print(f"   -> LDS bank conflict / LDS active  : {g(b, 'SQ_LDS_BANK_CONFLICT') / g(b, 'SQ_LDS_IDX_ACTIVE'):.4f}")
-        print(f"   -> SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_LDS : {g(b, 'SQ_ACTIVE_INST_VALU') / g(b, 'SQ_ACTIVE_INST_LDS'):.3f}")
+        cyc = g(b, "GRBM_GUI_ACTIVE") / 8.0            # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+        # SQ_VALU_MFMA_BUSY_CYCLES = cycles the matrix pipes are occupied, summed over the 1024 SIMDs (32 per 32x32x16 bf16 MFMA,
+        # 16 per 16x16x32): divided by 1024 x the kernel's cycles it is the fraction of the dense MFMA peak at the clock the kernel held
+        print(f"   -> kernel cycles (GRBM_GUI_ACTIVE / 8)             : {cyc:.4g}")
+        print(f"   -> MFMA pipe occupancy = MFMA_BUSY / (1024 x cycles) : {g(a, 'SQ_VALU_MFMA_BUSY_CYCLES') / (1024 * cyc):.3f}")
+        print(f"   -> MFMA instructions per VALU instruction            : {g(a, 'SQ_INSTS_MFMA') / g(a, 'SQ_INSTS_VALU'):.3f}")
+        print(f"   -> wave cycles waiting on anything / wave cycles     : {g(a, 'SQ_WAIT_INST_ANY') / wc:.3f}")
+        print(f"   -> wave cycles issuing / wave cycles                 : {g(a, 'SQ_ACTIVE_INST_ANY') / wc:.3f}")
+        print(f"   -> LDS bank-conflict cycles / LDS active cycles      : {g(b, 'SQ_LDS_BANK_CONFLICT') / g(b, 'SQ_LDS_IDX_ACTIVE'):.4f}")
+        print(f"   -> LDS array active / (256 CUs x cycles)             : {g(b, 'SQ_LDS_IDX_ACTIVE') / (256 * cyc):.3f}")
         print()
 
 
