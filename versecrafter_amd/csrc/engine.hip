@@ -12,6 +12,7 @@
 //   * q/k/v are written into one [M, 3d] buffer that the attention kernel reads through strides.
 // Sequence parallelism (WT.py:901-921, VC.py:269-270, 366-367, 432-433): contiguous token chunk per rank,
 // Ulysses head-scatter all-to-all around self-attention through host callbacks (torch.distributed / RCCL).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
@@ -43,6 +44,34 @@ struct BlockW {
 };
 
 thread_local std::string g_create_error;
+
+// Optional ROCTx ranges (VC_ROCTX=1 at vc_create): one range per vc_prepare_video / vc_forward and per DiT block, named like
+// the reference's modules ("blocks.17", "geoada_blocks.3"), so that `rocprofv3 --marker-trace --kernel-trace` groups the engine's
+// kernel launches by block.  The library is bound with dlopen; without the variable nothing is loaded and a range costs a branch.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx g_roctx;
+void roctx_enable() {
+    if (g_roctx.push) return;
+    void* lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    auto push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+    auto pop = (int (*)())dlsym(lib, "roctxRangePop");
+    if (push && pop) { g_roctx.pop = pop; g_roctx.push = push; }
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name, int idx = -1) : on(g_roctx.push != nullptr) {
+        if (!on) return;
+        char buf[64];
+        if (idx >= 0) { snprintf(buf, sizeof buf, "%s.%d", name, idx); g_roctx.push(buf); }
+        else g_roctx.push(name);
+    }
+    ~Range() { if (on) g_roctx.pop(); }
+};
 
 // scratch buffers + stream of one block chain.  Lane 0 = main chain on the caller's stream; lane 1 = GeoAdapter chain on
 // an engine-owned stream (used when the two chains run concurrently, see vc_forward).
@@ -509,6 +538,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     vc_engine* h = new vc_engine();
     h->cfg = *cfg;
     h->pad_merge = getenv("VC_NO_PAD_MERGE") == nullptr;
+    if (const char* rx = getenv("VC_ROCTX")) if (atoi(rx) == 1) roctx_enable();
     if (cfg->num_geoada_layers > 0) {
         if (cfg->num_geoada_layers > VC_MAX_GEOADA_LAYERS) { delete h; return fail(nullptr, VC_E_INVALID, "too many geoada layers"); }
         h->geoada_layers.assign(cfg->geoada_layers, cfg->geoada_layers + cfg->num_geoada_layers);
@@ -706,6 +736,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     if (T > 1024 || H / 2 > 1024 || Wd / 2 > 1024) return fail(h, VC_E_INVALID, "grid exceeds the 1024-row rope table");
     if (!h->rope_dev) return fail(h, VC_E_STATE, "vc_set_rope_table must be called first");
     { int r = resolve(h); if (r != VC_OK) return r; }
+    Range r_prep("vc_prepare_video");
     const vc_config& c = h->cfg;
     const int d = c.dim, f = c.ffn_dim, TL = c.text_len, P = h->P;
     const int L = T * (H / 2) * (Wd / 2);
@@ -840,6 +871,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                void* stream) {
     if (!h || !x || !t || !out) return fail(h, VC_E_INVALID, "vc_forward: null argument");
     if (!h->prepared) return fail(h, VC_E_STATE, "vc_forward before vc_prepare_video");
+    Range r_fwd("vc_forward");
     const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL,
                use_res = flags & VC_FWD_USE_RESIDUAL;
     const bool shared0 = (flags & VC_FWD_SHARED_CFG_INPUT) && h->B >= 2;   // see run_block(shared_sa)
@@ -884,6 +916,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
         // (on the rows of lane `la`'s samples)
         auto adapter_block = [&](int n, Lane& la, int nslots, bool shared) -> int {
+            Range r_blk("geoada_blocks", n);
             const BlockW& gb = h->gblocks[n];
             const int64_t ro = (int64_t)la.b0 * Lloc * d * 2;
             char* cc = (char*)h->c + ro;
@@ -905,7 +938,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             }
             int next_adapter = 0;
             { int r = adapter_block(next_adapter++, L0, 1, shared0); if (r != VC_OK) return r; }      // 0 in geoada_layers
-            { int r = run_block(h, h->blocks[0], h->x, h->hint[0], geoada_context_scale, L0, nullptr, nullptr, shared0);
+            { Range r_blk("blocks", 0);
+              int r = run_block(h, h->blocks[0], h->x, h->hint[0], geoada_context_scale, L0, nullptr, nullptr, shared0);
               if (r != VC_OK) return r; }
             // fork: sample 0 stays on the caller's stream, sample 1 moves to the engine's; both work in place on their rows of
             // the same buffers (activations are [B][Lloc][.] with the sample outermost), each with its own communicator
@@ -929,7 +963,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             }
             // one block of either chain for both samples.  Sample lanes: whole block per sample (the streams interleave them);
             // sample pipeline: phase by phase, alternating between the samples on the one compute stream
-            auto both = [&](const BlockW& w, bool adapter, int n_or_hint) -> int {
+            auto both = [&](const BlockW& w, bool adapter, int n_or_hint, int index) -> int {
+                Range r_blk(adapter ? "geoada_blocks" : "blocks", index);
                 const int nph = h->lane_mode == 3 ? 3 : 1;
                 for (int ph = 0; ph < nph; ++ph)
                     for (int b = 0; b < 2; ++b) {
@@ -949,8 +984,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
             for (int i = 1; i < c.num_layers; ++i) {
                 const int hn = h->layer_to_hint[i];
                 if (hn >= 0)
-                    for (; next_adapter <= hn; ++next_adapter) { int r = both(h->gblocks[next_adapter], true, next_adapter); if (r != VC_OK) return r; }
-                { int r = both(h->blocks[i], false, hn); if (r != VC_OK) return r; }
+                    for (; next_adapter <= hn; ++next_adapter) { int r = both(h->gblocks[next_adapter], true, next_adapter, next_adapter); if (r != VC_OK) return r; }
+                { int r = both(h->blocks[i], false, hn, i); if (r != VC_OK) return r; }
             }
             if (h->lane_mode == 2) {
                 HIPCHK(h, hipEventRecord(h->ev_bp, h->s_adp));           // join
@@ -973,6 +1008,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                         if (r != VC_OK) return r;
                         ++next_adapter;
                     }
+                Range r_blk("blocks", i);
                 int r = run_block(h, h->blocks[i], h->x, hn >= 0 ? h->hint[0] : nullptr, geoada_context_scale, L0, nullptr,
                                   nullptr, shared0 && i == 0);
                 if (r != VC_OK) return r;
