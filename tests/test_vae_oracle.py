@@ -49,3 +49,28 @@ def test_production_state_dict_inventory():
     assert shapes["decoder.upsamples.3.resample.1.weight"] == (192, 384, 3, 3)
     assert shapes["decoder.upsamples.4.shortcut.weight"] == (384, 192, 1, 1, 1)
     assert shapes["decoder.head.2.weight"] == (3, 96, 3, 3, 3)
+
+
+def test_mirror_inventory_equals_oracle_inventory_and_no_gpu_is_loud():
+    """The Python mirror's parameter inventory (what it registers and hands to vc_vae_load_weight) is the oracle's, key by key;
+    without a HIP device the engine refuses to construct (no CPU path)."""
+    import ctypes
+    from versecrafter_amd import _lib
+    from versecrafter_amd.models.wan_vae import AutoencoderKLWan, vae_state_dict_shapes
+    for cfgk in (dict(dim=96, z_dim=16), dict(dim=32, z_dim=16), dict(dim=64, z_dim=8)):
+        want = V.state_dict_shapes(V.Config(**cfgk))
+        assert vae_state_dict_shapes(cfgk["dim"], cfgk["z_dim"]) == want
+    m = AutoencoderKLWan(dim=32, param_device="meta")
+    assert {k: tuple(p.shape) for k, p in m.named_parameters()} == V.state_dict_shapes(V.Config(dim=32, z_dim=16))
+    assert m.config.latent_channels == 16 and m.spacial_compression_ratio == 8
+    if not torch.cuda.is_available():
+        lib = _lib.load()
+        cfg = _lib.vc_vae_config()
+        cfg.dim, cfg.z_dim, cfg.num_res_blocks = 32, 16, 2
+        for i, v in enumerate((1, 2, 4, 4)):
+            cfg.dim_mult[i] = v
+        for i, v in enumerate((0, 1, 1)):
+            cfg.temporal_downsample[i] = v
+        h = ctypes.c_void_p()
+        assert lib.vc_vae_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.VC_E_HIP
+        assert b"no HIP device" in lib.vc_vae_last_error(None)
