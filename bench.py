@@ -312,7 +312,7 @@ def run_rank(args):
         f_step = step_flops(mk["dim"], mk["ffn_dim"], NL, NA, L, 2, mk.get("text_len", 512), text_dim)
         sps = args.steps / elapsed
         out = {
-            "metric": "denoise-steps/sec Wan2.1-14B+GeoAdapter 81fx480p" if args.workload.startswith("wan14b-81f")
+            "metric": "denoise-steps/sec Wan2.1-14B+GeoAdapter 81fx480p" if args.workload == "wan14b-81f-480x832"
                       else f"denoise-steps/sec {args.workload}",
             "value": sps, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
