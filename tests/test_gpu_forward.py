@@ -575,3 +575,29 @@ def test_time_embedding_vs_oracle(model):
     err = (got - e0).abs().max().item()
     print(f"time embedding: max abs err {err:.3g} (|e0| max {e0.abs().max():.3g})")
     assert torch.allclose(got, e0, rtol=1e-4, atol=1e-4 * float(e0.abs().max()))       # fp32 dot products, different summation order
+
+
+def test_graph_replay_equals_eager_bitwise(fwd, monkeypatch):
+    """Launch-bound sizes replay a captured hipGraph from the second forward with a (flags, scale) key on: inputs staged in,
+    graph launched on the caller's stream, output staged out.  Every replay must equal the eager engine (VC_GRAPH=0) bit for
+    bit -- changing latents and timesteps, a second scale (its own graph), the TeaCache flag pairs, and a non-default stream."""
+    L = int(fwd["A.seq_len"])
+    xs = [fwd["A.x"], fwd["C.x2"], fwd["A.x"] * 0.5, fwd["C.x2"] * 0.75, fwd["A.x"] * -0.3]
+    ts = [fwd["C.t1"], fwd["C.t2"], fwd["C.t2"] - 40.0, fwd["C.t2"] - 80.0, fwd["C.t2"] - 120.0]
+    monkeypatch.setenv("VC_GRAPH", "0")
+    eager = _fresh_model()
+    monkeypatch.setenv("VC_GRAPH", "1")
+    graph = _fresh_model()
+    for i in range(5):
+        for scale in (1.0, 0.6):
+            assert torch.equal(run(graph, fwd, L, x=xs[i], t=ts[i], scale=scale), run(eager, fwd, L, x=xs[i], t=ts[i], scale=scale)), (i, scale)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        a = run(graph, fwd, L, x=xs[1], t=ts[1])
+    side.synchronize()
+    assert torch.equal(a, run(eager, fwd, L, x=xs[1], t=ts[1]))
+    for m in (eager, graph):
+        m.enable_teacache([1.0, 0.0], num_steps=6, rel_l1_thresh=1e9, num_skip_start_steps=2, offload=False)
+    for i in range(5):                               # calc, calc, skip, skip, skip: STORE graphs, then USE graphs
+        assert torch.equal(run(graph, fwd, L, x=xs[i], t=ts[i]), run(eager, fwd, L, x=xs[i], t=ts[i])), i
+        assert graph.should_calc == eager.should_calc == (i < 2)

@@ -145,6 +145,17 @@ struct vc_engine {
     float *f_sin, *f_h, *f_e, *f_e0;
     void* small = nullptr;   // fp32 scratch for vc_time_embedding before prepare
 
+    // hipGraph replay of launch-bound forwards (small token counts: a 1.3B / 9-frame step is ~800 launches of a few tens of
+    // microseconds each).  One graph per (flags, geoada_context_scale): the first forward with a key runs eagerly (sets kernel
+    // attributes, allocates TeaCache slots), the second is captured on an engine stream against staging copies of x / t / out,
+    // later ones copy the inputs in, launch the graph on the caller's stream and copy the result out.  One rank, one stream,
+    // profiling off only; VC_GRAPH=0 / 1 forces it off / on (default: rows M <= 16384).
+    struct GraphEntry { uint32_t flags; float scale; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    int graph_mode = -1;            // -1 auto, 0 off, 1 on
+    hipStream_t s_cap = nullptr;
+    void *gx = nullptr, *gt = nullptr, *gy = nullptr;      // staging: x in, t in, out
+
     // optional per-kernel-class timing (vc_profile_*): HIP event pairs around every launch of a class
     bool prof_on = false;
     struct ProfRec { int cls; hipEvent_t a, b; double flops; double bytes; };
@@ -505,7 +516,16 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     return VC_OK;
 }
 
+void drop_graphs(vc_engine* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+}
+
 void free_arena(vc_engine* h) {
+    drop_graphs(h);                 // the graphs' kernel arguments point into the arena
     if (h->arena) (void)hipFree(h->arena);
     h->arena = nullptr;
     h->arena_bytes = 0;
@@ -539,6 +559,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     h->cfg = *cfg;
     h->pad_merge = getenv("VC_NO_PAD_MERGE") == nullptr;
     if (const char* rx = getenv("VC_ROCTX")) if (atoi(rx) == 1) roctx_enable();
+    if (const char* gm = getenv("VC_GRAPH")) h->graph_mode = atoi(gm) != 0;
     if (cfg->num_geoada_layers > 0) {
         if (cfg->num_geoada_layers > VC_MAX_GEOADA_LAYERS) { delete h; return fail(nullptr, VC_E_INVALID, "too many geoada layers"); }
         h->geoada_layers.assign(cfg->geoada_layers, cfg->geoada_layers + cfg->num_geoada_layers);
@@ -592,6 +613,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     const size_t na = h->geoada_layers.size();
     h->ev_hint.resize(na); h->ev_used.resize(na);
     bool ok = hipStreamCreateWithFlags(&h->s_adp, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->s_cap, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->s_comm[0], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->s_comm[1], hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) == hipSuccess &&
@@ -609,6 +631,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
 void vc_destroy(vc_engine* h) {
     if (!h) return;
     if (h->s_adp) { (void)hipStreamSynchronize(h->s_adp); (void)hipStreamDestroy(h->s_adp); }
+    if (h->s_cap) (void)hipStreamDestroy(h->s_cap);
     for (int l = 0; l < 2; ++l) {
         if (h->s_comm[l]) { (void)hipStreamSynchronize(h->s_comm[l]); (void)hipStreamDestroy(h->s_comm[l]); }
         for (int k = 0; k < 4; ++k) if (h->ev_lane[l][k]) (void)hipEventDestroy(h->ev_lane[l][k]);
@@ -636,6 +659,7 @@ int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype
     if (!same) return fail(h, VC_E_INVALID, "vc_load_weight(%s): size mismatch", key);   // WT.py:1304-1307
     if ((uintptr_t)dev_ptr % 16) return fail(h, VC_E_INVALID, "vc_load_weight(%s): pointer not 16-byte aligned", key);
     it->second.ptr = dev_ptr;
+    drop_graphs(h);
     h->resolved = false;
     h->prepared = false;   // cached cross-attention K/V depend on the weights
     return VC_OK;
@@ -653,6 +677,7 @@ int vc_set_rope_table(vc_engine* h, const double* cis, int rows, int cols) {
     if (rows != 1024 || cols != 64) return fail(h, VC_E_UNSUPPORTED, "rope table must be [1024][64] (head dim 128)");
     std::vector<float2> t((size_t)rows * cols);
     for (size_t i = 0; i < t.size(); ++i) t[i] = make_float2((float)cis[2 * i], (float)cis[2 * i + 1]);
+    drop_graphs(h);
     if (!h->rope_dev) HIPCHK(h, hipMalloc(&h->rope_dev, t.size() * sizeof(float2)));
     HIPCHK(h, hipMemcpy(h->rope_dev, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
     return VC_OK;
@@ -785,6 +810,8 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     const int64_t o_headmod = take((int64_t)B * 2 * d * 2);
     const int64_t yb = (int64_t)M * c.out_dim * 4 * 2;
     const int64_t o_y = take(yb), o_yfull = take(yb * P);
+    const int64_t o_gx = take((int64_t)B * c.in_dim * T * H * Wd * 2), o_gy = take((int64_t)B * c.out_dim * T * H * Wd * 2),
+                  o_gt = take((int64_t)B * 4);
     const int64_t o_fsin = take((int64_t)B * c.freq_dim * 4), o_fh = take((int64_t)B * d * 4),
                   o_fe = take((int64_t)B * d * 4), o_fe0 = take((int64_t)B * 6 * d * 4);
     const int64_t kvb = (int64_t)B * TL * d * 2;
@@ -806,6 +833,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     h->x = a + o_x; h->c = a + o_c; h->c0 = a + o_c0; h->patchA = a + o_patch;
     h->ctxpad = a + o_ctxpad; h->ctxh = a + o_ctxh; h->ctx = a + o_ctx; h->headmod = a + o_headmod;
     h->ybuf = a + o_y; h->yfull = a + o_yfull;
+    h->gx = a + o_gx; h->gy = a + o_gy; h->gt = a + o_gt;
     for (int l = 0; l < 2; ++l) {
         h->hint[l] = a + o_hint[l];
         Lane& ln = h->lane[l];
@@ -867,20 +895,13 @@ int vc_time_embedding(vc_engine* h, const float* t, int B, float* e0_out, void* 
     return time_embed(h, t, B, fs, fh, fe, e0_out, (hipStream_t)stream);
 }
 
-int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geoada_context_scale, uint32_t flags,
-               void* stream) {
-    if (!h || !x || !t || !out) return fail(h, VC_E_INVALID, "vc_forward: null argument");
-    if (!h->prepared) return fail(h, VC_E_STATE, "vc_forward before vc_prepare_video");
-    Range r_fwd("vc_forward");
-    const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL,
-               use_res = flags & VC_FWD_USE_RESIDUAL;
+// the launch sequence of one forward (no host-visible state changes: vc_forward does those, so that a captured graph and an
+// eager run leave the handle in the same state)
+static int forward_impl(vc_engine* h, const void* x, const float* t, void* out, float geoada_context_scale, uint32_t flags,
+                        hipStream_t s) {
+    const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL;
     const bool shared0 = (flags & VC_FWD_SHARED_CFG_INPUT) && h->B >= 2;   // see run_block(shared_sa)
-    if (run_main == use_res) return fail(h, VC_E_INVALID, "vc_forward: exactly one of RUN_MAIN_BLOCKS / USE_RESIDUAL");
     const int slot = (flags & VC_FWD_RESIDUAL_UNCOND) ? 1 : 0;
-    if (use_res && (h->resid_B[slot] < h->B || h->resid_L[slot] != h->Lloc))
-        return fail(h, VC_E_STATE, "vc_forward: no stored %s residual for %d sample(s) to re-use (stored: %d)",
-                    slot ? "uncond" : "cond", h->B, h->resid_L[slot] == h->Lloc ? h->resid_B[slot] : 0);
-    hipStream_t s = (hipStream_t)stream;
     const vc_config& c = h->cfg;
     const int d = c.dim, M = h->M, B = h->B, Lloc = h->Lloc;
     const int64_t md = (int64_t)M * d * 2;
@@ -899,19 +920,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     Lane& L0 = h->lane[0];
     L0.idx = 0; L0.s = s; L0.b0 = 0; L0.nb = B;
     if (run_main) {
-        if (store_res) {                                     // ori_x = x.clone()  (VC.py:398)
-            if (h->resid_cap[slot] < md) {                   // first use of the slot (or a larger batch): one-time allocation
-                if (h->resid[slot]) HIPCHK(h, hipFree(h->resid[slot]));
-                h->resid[slot] = nullptr; h->resid_cap[slot] = 0; h->resid_B[slot] = 0;
-                if (hipMalloc(&h->resid[slot], md) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return fail(h, VC_E_NOMEM, "hipMalloc of the %lld-byte TeaCache residual failed", (long long)md);
-                }
-                h->resid_cap[slot] = md;
-            }
-            h->resid_B[slot] = 0;
+        if (store_res)                                       // ori_x = x.clone()  (VC.py:398); slot allocated by vc_forward
             HIPCHK(h, hipMemcpyAsync(h->resid[slot], h->x, md, hipMemcpyDeviceToDevice, s));
-        }
         const int NA = (int)h->gblocks.size();
         // adapter block n on lane `la`: c = block(c); hint_n = after_proj(c) into ring slot n % nslots
         // (on the rows of lane `la`'s samples)
@@ -1052,10 +1062,8 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
                 }
             }
         }
-        if (store_res) {                                     // previous_residual_cond = x - ori_x (VC.py:409)
+        if (store_res)                                       // previous_residual_cond = x - ori_x (VC.py:409)
             VCCHK(h, vc_launch_sub(h->x, h->resid[slot], h->resid[slot], (int64_t)M * d, s));
-            h->resid_B[slot] = B; h->resid_L[slot] = Lloc;
-        }
     } else {
         // x = x + previous_residual[-B:]  (VC.py:390-396: the last B samples of what was stored)
         const char* pr = (const char*)h->resid[slot] + (int64_t)(h->resid_B[slot] - B) * Lloc * d * 2;
@@ -1085,6 +1093,70 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     }
     VCCHK(h, vc_launch_unpatchify(y, out, B, c.out_dim, h->T, h->H2, h->W2, Lloc, s));
     return VC_OK;
+}
+
+int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geoada_context_scale, uint32_t flags,
+               void* stream) {
+    if (!h || !x || !t || !out) return fail(h, VC_E_INVALID, "vc_forward: null argument");
+    if (!h->prepared) return fail(h, VC_E_STATE, "vc_forward before vc_prepare_video");
+    Range r_fwd("vc_forward");
+    const bool run_main = flags & VC_FWD_RUN_MAIN_BLOCKS, store_res = flags & VC_FWD_STORE_RESIDUAL,
+               use_res = flags & VC_FWD_USE_RESIDUAL;
+    if (run_main == use_res) return fail(h, VC_E_INVALID, "vc_forward: exactly one of RUN_MAIN_BLOCKS / USE_RESIDUAL");
+    const int slot = (flags & VC_FWD_RESIDUAL_UNCOND) ? 1 : 0;
+    if (use_res && (h->resid_B[slot] < h->B || h->resid_L[slot] != h->Lloc))
+        return fail(h, VC_E_STATE, "vc_forward: no stored %s residual for %d sample(s) to re-use (stored: %d)",
+                    slot ? "uncond" : "cond", h->B, h->resid_L[slot] == h->Lloc ? h->resid_B[slot] : 0);
+    hipStream_t s = (hipStream_t)stream;
+    const vc_config& c = h->cfg;
+    const int64_t md = (int64_t)h->M * c.dim * 2;
+    if (run_main && store_res) {
+        if (h->resid_cap[slot] < md) {                       // first use of the slot (or a larger batch): one-time allocation
+            drop_graphs(h);                                  // (a graph captured earlier holds the old pointer)
+            if (h->resid[slot]) HIPCHK(h, hipFree(h->resid[slot]));
+            h->resid[slot] = nullptr; h->resid_cap[slot] = 0;
+            if (hipMalloc(&h->resid[slot], md) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(h, VC_E_NOMEM, "hipMalloc of the %lld-byte TeaCache residual failed", (long long)md);
+            }
+            h->resid_cap[slot] = md;
+        }
+        h->resid_B[slot] = 0;
+    }
+    // ---- eager, or through a captured graph (launch-bound sizes) ----
+    const bool small = h->M <= 16384;
+    const bool graph_ok = h->lane_mode == 0 && !h->sp_exchange && !h->prof_on && (h->graph_mode < 0 ? small : h->graph_mode == 1);
+    int rc = VC_OK;
+    vc_engine::GraphEntry* ge = nullptr;
+    if (graph_ok) {
+        for (auto& g : h->graphs)
+            if (g.flags == flags && g.scale == geoada_context_scale) ge = &g;
+        if (!ge) { h->graphs.push_back({flags, geoada_context_scale, 0, nullptr, nullptr}); ge = &h->graphs.back(); }
+    }
+    if (ge && ge->seen == 1 && !ge->exec) {                  // second forward with this key: capture
+        bool ok = hipStreamBeginCapture(h->s_cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int crc = forward_impl(h, h->gx, (const float*)h->gt, h->gy, geoada_context_scale, flags, h->s_cap);
+            hipGraph_t g = nullptr;
+            ok = hipStreamEndCapture(h->s_cap, &g) == hipSuccess && crc == VC_OK && g != nullptr;
+            if (ok) ok = hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) ge->graph = g;
+            else { if (g) (void)hipGraphDestroy(g); ge->exec = nullptr; }
+        }
+        if (!ok) { (void)hipGetLastError(); ge->seen = -1; }  // capture is not available for this call pattern: stay eager
+    }
+    if (ge && ge->exec) {
+        const int64_t nx = (int64_t)h->B * c.in_dim * h->T * h->H * h->W * 2, ny = (int64_t)h->B * c.out_dim * h->T * h->H * h->W * 2;
+        HIPCHK(h, hipMemcpyAsync(h->gx, x, (size_t)nx, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->gt, t, (size_t)h->B * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipGraphLaunch(ge->exec, s));
+        HIPCHK(h, hipMemcpyAsync(out, h->gy, (size_t)ny, hipMemcpyDeviceToDevice, s));
+    } else {
+        rc = forward_impl(h, x, t, out, geoada_context_scale, flags, s);
+        if (ge && ge->seen == 0) ge->seen = 1;
+    }
+    if (rc == VC_OK && run_main && store_res) { h->resid_B[slot] = h->B; h->resid_L[slot] = h->Lloc; }
+    return rc;
 }
 
 int vc_profile_enable(vc_engine* h, int on) {
