@@ -22,6 +22,10 @@
 #include "vc_common.h"
 #include "vc_kernels.h"
 
+#ifndef VC_GEMM_SMALL_TILES
+#define VC_GEMM_SMALL_TILES 384     // below this many 256 x 256 tiles the 128 x 128 kernel is used (see vc_launch_gemm)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -532,6 +536,10 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
         if (!p.Wg[g - 1] || !p.Cg[g - 1]) return VC_E_INVALID;
     // p.tile (tests / tuning): 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel
     bool big = (p.M >= 1024 && p.N >= 256);
+    // small problems (a 1.3B model on a 9-frame clip: M = 3840, N = 1536 -> 90 tiles of 256 x 256 for 256 CUs): 128 x 128 tiles,
+    // two workgroups per CU, fill the chip where the big tile leaves two thirds of it idle; same K order, bit-identical results
+    const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ngroups > 1 ? p.ngroups : 1);
+    if (t256 < VC_GEMM_SMALL_TILES) big = false;
     if (p.tile == 1) big = false;
     if (p.tile == 2) big = true;
     // every tile row readable (M a multiple of 256 or padded buffers), N % 256 == 0, K % 128 == 0: ping-pong kernel
