@@ -23,7 +23,7 @@
 #include "vc_kernels.h"
 
 #ifndef VC_GEMM_SMALL_TILES
-#define VC_GEMM_SMALL_TILES 384     // below this many 256 x 256 tiles the 128 x 128 kernel is used (see vc_launch_gemm)
+#define VC_GEMM_SMALL_TILES 256     // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel is used (see vc_launch_gemm)
 #endif
 
 namespace {
