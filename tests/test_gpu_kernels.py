@@ -140,14 +140,16 @@ def _padded_rows(t, mult=256):
     return buf[:M]
 
 
+@pytest.mark.parametrize("tile", [4, 5])
 @pytest.mark.parametrize("M,N,K", [(1024, 256, 128), (1100, 512, 1024), (2047, 768, 384), (4096, 1280, 2560)])
-def test_gemm_pingpong_bias(ops, M, N, K):
-    """tile=4: the 8-phase ping-pong kernel (production path for the engine's big GEMMs) against the oracle and,
-    bit for bit, against the 2-stage kernel (same K order => same fp32 sums)."""
+def test_gemm_pingpong_bias(ops, M, N, K, tile):
+    """tile=4: the 8-phase ping-pong kernel (production path for the engine's big GEMMs), tile=5: the one-wave-per-SIMD
+    kernel (4 waves x 128x128, accumulators in AGPRs; tuning alternative) against the oracle and, bit for bit, against
+    the 2-stage kernel (same K order => same fp32 sums)."""
     rs = np.random.RandomState(M + N + K)
     a, w, b = bf(rs_randn(rs, M, K)), bf(rs_randn(rs, N, K, scale=K ** -0.5)), bf(rs_randn(rs, N, scale=0.1))
     ap = _padded_rows(a)
-    got = ops.gemm(ap, dev(w), dev(b), tile=4)
+    got = ops.gemm(ap, dev(w), dev(b), tile=tile)
     torch.cuda.synchronize()
     assert_bf16_close(got, O.linear(a.float(), w.float(), b.float()), ulps=1.01, atol=2e-3, what="pingpong bias")
     assert torch.equal(got, ops.gemm(ap, dev(w), dev(b), tile=2))
@@ -169,6 +171,8 @@ def test_gemm_pingpong_epilogues_and_race_screen(ops):
         want = ops.gemm(ap, dev(w), dev(b), tile=2, **k)       # tile 2 is checked against the oracle above
         for _ in range(25):                                    # staging races show up as rare wrong tiles
             assert torch.equal(ops.gemm(ap, dev(w), dev(b), tile=4, **k), want)
+        for _ in range(10):
+            assert torch.equal(ops.gemm(ap, dev(w), dev(b), tile=5, **k), want)
 
 
 # ------------------------------------------------------------------------------- control-map front-end

@@ -86,7 +86,7 @@ VC_DEVICE void stage_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_
     }
 }
 
-template <class Cfg, bool SB>
+template <class Cfg, bool SB, int EPI>
 __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MI = Cfg::MI, NI = Cfg::NI;
@@ -232,20 +232,20 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += bb[e];
             }
-            if (p.epilogue == VC_EPI_BIAS_GELU) {
+            if (EPI == VC_EPI_BIAS_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
-            } else if (p.epilogue == VC_EPI_BIAS_RESID) {
+            } else if (EPI == VC_EPI_BIAS_RESID) {
                 float r[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
-            } else if (p.epilogue == VC_EPI_GELU_MUL) {
+            } else if (EPI == VC_EPI_GELU_MUL) {
                 float r[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
-            } else if (p.epilogue == VC_EPI_BIAS_GATE_RESID) {
+            } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
                 float r[4], g[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
                 unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), g);
@@ -285,8 +285,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 // WAR: a half is restaged two phases after its last read.  RAW: the counted vmcnt (all but the two youngest half-tiles)
 // sits before a barrier that every reader passes before its first read of that K-tile, one phase later.
 // Rows past M are read (never stored): the caller guarantees they are readable (a_rows_padded / M % 256 == 0).
-// Past the last K-tile the staging re-reads the last K-tile into a dead stage (keeps vmcnt counts uniform).
+// Past the last K-tile the staging re-reads the last two K-tiles into dead stages (keeps vmcnt counts uniform).
+// The epilogue kind is a template parameter (here and in the other kernels): with all five kinds inline behind run-time
+// branches this kernel was 52 KB of code, most of it unrolled epilogue, against a 64 KB instruction cache shared by two
+// CUs; per kind it is 11-24 KB (round 2: 0-2 % at the cfg-3 shapes, same-box A/B).
 // =====================================================================================================
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int per_xcd = gridDim.x >> 3;
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+
     auto uniform_ptr = [](const char* q) {     // force a wave-uniform address into an SGPR pair
         const uint64_t u = (uint64_t)q;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
@@ -329,7 +334,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 
     // region: 0 Ah0, 1 Ah1, 2 Bh0, 3 Bh1
     auto stage_half = [&](int stage, int region, int kt) {
-        kt = kt < nk ? kt : nk - 1;
         const bool isA = region < 2;
         const int hh = region & 1;
         const char* s0 = isA ? a_src + (int64_t)hh * 64 * lda2 : w_src + (int64_t)hh * 32 * ldw2;
@@ -401,20 +405,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     read_b(0, 0);                          // B0 of K-tile 0 (later ones are read during the previous K-tile's 4th phase)
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < nk; kt += 2) {
+    // One pair of K-tiles (8 phases).  Loads issued during the pair fill K-tiles kt+1 (its Ah1), kt+2 and kt+3 (minus its Ah1);
+    // in the LAST pair of the tile what would lie past K-tile nk-1 re-reads the last two K-tiles into dead stages (never read;
+    // keeps the vmcnt counts uniform without a clamp in the hot loop).
+    auto pair = [&](int kt, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        auto stage_ahead = [&](int stage, int region, int off) __attribute__((always_inline)) {
+            stage_half(stage, region, LAST && off >= 2 ? kt + off - 2 : kt + off);
+        };
 #pragma unroll
         for (int st = 0; st < 2; ++st) {     // st = 0: K-tile kt (even stage), st = 1: K-tile kt+1 (odd stage)
             // phase 1 / 5: reads A0
             read_a(st, 0);
             __builtin_amdgcn_sched_barrier(0);
-            stage_half(st ^ 1, 1, kt + 1 + st);                 // Ah1 of the other stage's next K-tile
+            stage_ahead(st ^ 1, 1, 1 + st);                     // Ah1 of the other stage's next K-tile
             VC_PP_BARRIER();
             mma(0, 0, st);
             VC_PP_BARRIER();
             // phase 2 / 6: reads B1
             read_b(st, 1);
             __builtin_amdgcn_sched_barrier(0);
-            stage_half(st, 2, kt + 2 + st);                      // Bh0 of this stage's next K-tile
+            stage_ahead(st, 2, 2 + st);                         // Bh0 of this stage's next K-tile
             VC_PP_BARRIER();
             mma(0, 1, st);
             VC_PP_BARRIER();
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             // youngest half-tiles are retired
             read_a(st, 1);
             __builtin_amdgcn_sched_barrier(0);
-            stage_half(st, 0, kt + 2 + st);                      // Ah0
+            stage_ahead(st, 0, 2 + st);                         // Ah0
             VC_PP_WAIT("s_waitcnt vmcnt(4)");
             VC_PP_BARRIER();
             mma(1, 1, st);
@@ -430,12 +441,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             // phase 4 / 8: reads B0 of the NEXT K-tile (other stage; its set of registers held this K-tile's B1)
             read_b(st ^ 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            stage_half(st, 3, kt + 2 + st);                      // Bh1
+            stage_ahead(st, 3, 2 + st);                         // Bh1
             VC_PP_BARRIER();
             mma(1, 0, st);
             VC_PP_BARRIER();
         }
-    }
+    };
+    for (int kt = 0; kt < nk - 2; kt += 2) pair(kt, std::false_type{});
+    pair(nk - 2, std::true_type{});
     if (wr == 0) VC_PP_BARRIER();          // equalise the barrier count
     VC_PP_WAIT("s_waitcnt vmcnt(0)");      // nothing may still be landing in LDS when the workgroup retires
 #undef VC_PP_BARRIER
@@ -465,20 +478,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += bb[e];
             }
-            if (p.epilogue == VC_EPI_BIAS_GELU) {
+            if (EPI == VC_EPI_BIAS_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
-            } else if (p.epilogue == VC_EPI_BIAS_RESID) {
+            } else if (EPI == VC_EPI_BIAS_RESID) {
                 float r[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
-            } else if (p.epilogue == VC_EPI_GELU_MUL) {
+            } else if (EPI == VC_EPI_GELU_MUL) {
                 float r[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
-            } else if (p.epilogue == VC_EPI_BIAS_GATE_RESID) {
+            } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
                 float r[4], gg[4];
                 unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
                 unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), gg);
@@ -497,29 +510,298 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     }
 }
 
-int launch_pp(const VcGemmParams& p, hipStream_t stream) {
+template <int EPI>
+int launch_pp_e(const VcGemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 65536;
     static std::atomic<uint64_t> attr_done{0};
-    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel, LDS)) return VC_E_HIP;
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel<EPI>, LDS)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
+    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
+int launch_pp(const VcGemmParams& p, hipStream_t stream) {
+    switch (p.epilogue) {
+        case VC_EPI_BIAS: return launch_pp_e<VC_EPI_BIAS>(p, stream);
+        case VC_EPI_BIAS_GELU: return launch_pp_e<VC_EPI_BIAS_GELU>(p, stream);
+        case VC_EPI_BIAS_RESID: return launch_pp_e<VC_EPI_BIAS_RESID>(p, stream);
+        case VC_EPI_BIAS_GATE_RESID: return launch_pp_e<VC_EPI_BIAS_GATE_RESID>(p, stream);
+        case VC_EPI_GELU_MUL: return launch_pp_e<VC_EPI_GELU_MUL>(p, stream);
+    }
+    return VC_E_INVALID;
+}
 
-template <class Cfg, bool SB = false>
-int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
+// =====================================================================================================
+// One-wave-per-SIMD kernel (round 2 experiment, tile id 5): 256x256x64 tile, 4 waves (2 x 2, 128x128 each), accumulators
+// in the 256 AGPRs, 2 LDS stages of 64 KiB, ONE barrier per K-tile.  Where the ping-pong kernel alternates whole 16-MFMA
+// sections with load sections across the two waves of a SIMD (16 barriers per two K-tiles), here a single wave interleaves
+// its own fragment reads and DMA issue between MFMAs (1 read per 4 MFMA): the 128x128 wave tile reads 32 KiB of fragments
+// per K-tile instead of 2 x 24 KiB, and nothing but the barrier ever idles the matrix pipe.
+//   K-tile kt (stage s = kt & 1), two steps of 64 MFMA (k = 0..31, 32..63):
+//     step 0: MFMA on F0                     | reads F1 <- (kt, k 32..63) from stage s
+//             vmcnt(0): K-tile kt+1 landed (issued one K-tile ago) ; barrier   (every wave is past its reads of stage s)
+//     step 1: MFMA on F1 | DMA K-tile kt+2 -> stage s | reads F0 <- (kt+1, k 0..31) from stage s^1
+// Same LDS image per row as the ping-pong kernel (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7), stage =
+// [A rows 0..255 | B rows 0..255]; same K order per accumulator -> bit-identical results.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_sw_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per_xcd = gridDim.x >> 3;
+    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (id >= ntiles) return;
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * nTn;
+    const int group = id / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(nTm - first_m, GROUP_M);
+    const int tm = first_m + (id % width) % gsz;
+    int tn = (id % width) / gsz;
+    const int nTn1 = p.ngroups > 1 ? nTn / p.ngroups : nTn;
+    const int grp = tn / nTn1;
+    tn -= grp * nTn1;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    auto uniform_ptr = [](const char* q) {
+        const uint64_t u = (uint64_t)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
+    const int64_t lda2 = p.lda * 2, ldw2 = p.ldw * 2;
+    // staging: a K-tile is 64 pieces of 8 rows (32 of A, 32 of B); wave w moves pieces w, w+4, ... of each (8 + 8 per K-tile);
+    // all have the parity of w, so the lane's swizzled chunk is one constant
+    const int r8 = lane >> 3;
+    const int chunk = (lane & 7) ^ ((r8 >> 1) + 4 * (wave & 1));
+    const unsigned voff_a = (unsigned)(r8 * lda2 + chunk * 16);
+    const unsigned voff_w = (unsigned)(r8 * ldw2 + chunk * 16);
+    unsigned voff_a_t[8], voff_w_t[8];      // piece t of a K-tile: 32 rows further down (lane offsets: one scalar base per K-tile)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        voff_a_t[t] = voff_a + (unsigned)(t * 32 * lda2);
+        voff_w_t[t] = voff_w + (unsigned)(t * 32 * ldw2);
+    }
+    const char* a_src = uniform_ptr((const char*)p.A + ((int64_t)m0 + 8 * wave) * lda2);
+    const char* w_src = uniform_ptr((const char*)(grp == 0 ? p.W : p.Wg[grp - 1]) + ((int64_t)n0 + 8 * wave) * ldw2);
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)smem + wave * 1024);
+    const int nk = p.K >> 6;
+
+    // piece t (0..7) of A (isA) or B of K-tile kt into `stage`
+    auto dma = [&](int stage, bool isA, int t, int kt) {
+        const char* s0 = (isA ? a_src + (int64_t)t * 32 * lda2 : w_src + (int64_t)t * 32 * ldw2) + (int64_t)kt * 128;
+        const unsigned d0 = lds_wave + stage * 65536 + (isA ? 0 : 32768) + t * 4096;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[s0]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [d0] "s"(d0), [v] "v"(isA ? voff_a : voff_w), [s0] "s"(s0)
+            : "memory", "scc");
+    };
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int sw = (lane >> 1) & 7;
+    const int pc[2] = {((lane >> 4) ^ sw) << 4, ((4 + (lane >> 4)) ^ sw) << 4};
+    const char* a_rd = smem + (wr * 128 + frow) * 128;
+    const char* b_rd = smem + 32768 + (wc * 128 + frow) * 128;
+    bf16x8 fa[2][8], fb[2][8];              // fragment sets F0 / F1: fa[set][i], fb[set][j]
+    // fragment number f (0..15) of K-half ks of the K-tile in `stage` into set `set`: f < 8 -> B block f, else A block f-8
+    // (the order the next step's MFMAs first need them in: all of B and A block 0 within its first 8 MFMAs)
+    auto read_frag = [&](int set, int stage, int ks, int f) {
+        if (f < 8) fb[set][f] = *(const bf16x8*)(b_rd + stage * 65536 + f * 2048 + pc[ks]);
+        else       fa[set][f - 8] = *(const bf16x8*)(a_rd + stage * 65536 + (f - 8) * 2048 + pc[ks]);
+    };
+    // MFMA number q (0..63) of a step, ordered so that consecutive MFMAs share neither accumulator nor (where possible) wait
+    // on the same late fragment: row block i = q / 8, column block j = q % 8
+    auto mma1 = [&](int set, int q) {
+        const int i = q >> 3, j = q & 7;
+        // accumulator tied to itself in AGPRs by hand: with all 256 in use the register allocator otherwise routes every
+        // MFMA's C operand through a scratch tuple (4 v_accvgpr_mov per MFMA)
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[set][j]), "v"(fa[set][i]));
+    };
+#define VC_SW_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: K-tiles 0 and 1 in flight, F0 <- (0, k 0..31) ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { dma(0, true, t, 0); dma(0, false, t, 0); }
+    if (nk > 1) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { dma(1, true, t, 1); dma(1, false, t, 1); }
+        VC_SW_FENCE(); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); VC_SW_FENCE();
+    } else {
+        VC_SW_FENCE(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VC_SW_FENCE();
+    }
+    __builtin_amdgcn_s_barrier();
+    VC_SW_FENCE();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) read_frag(0, 0, 0, f);
+
+    auto ktile = [&](int kt, auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const int s = kt & 1;
+        // ---- step 0: MFMA on F0; F1 <- second K-half of this K-tile ----
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            read_frag(1, s, 1, g);
+            VC_SW_FENCE();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mma1(0, g * 4 + q);
+            VC_SW_FENCE();
+        }
+        // K-tile kt+1 (this wave's pieces) landed; after the barrier: everyone's pieces, and nobody reads stage s any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VC_SW_FENCE();
+        __builtin_amdgcn_s_barrier();
+        VC_SW_FENCE();
+        // ---- step 1: MFMA on F1; K-tile kt+2 -> stage s; F0 <- first K-half of K-tile kt+1 ----
+        // the 16 pieces of K-tile kt+2 land at consecutive 4 KiB steps of this wave's LDS window (8 of A, then 8 of B): M0 is
+        // set once and stepped, and each load sits between two MFMAs (the M0 write needs a wait state before its use)
+        const char* a_k = a_src + (int64_t)(kt + 2) * 128;
+        const char* w_k = w_src + (int64_t)(kt + 2) * 128;
+        if (MORE) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_wave + s * 65536 - 4096) : "memory");
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            read_frag(0, s ^ 1, 0, g);
+            VC_SW_FENCE();
+            if (MORE) {
+                const int q0 = g * 4;
+                asm volatile(
+                    "s_add_u32 m0, m0, 0x1000\n\t"
+                    "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+                    "global_load_lds_dwordx4 %12, %13\n\t"
+                    "v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n\t"
+                    "v_mfma_f32_16x16x32_bf16 %2, %6, %10, %2\n\t"
+                    "v_mfma_f32_16x16x32_bf16 %3, %7, %11, %3"
+                    : "+a"(acc[(q0 + 0) >> 3][(q0 + 0) & 7]), "+a"(acc[(q0 + 1) >> 3][(q0 + 1) & 7]),
+                      "+a"(acc[(q0 + 2) >> 3][(q0 + 2) & 7]), "+a"(acc[(q0 + 3) >> 3][(q0 + 3) & 7])
+                    : "v"(fb[1][(q0 + 0) & 7]), "v"(fb[1][(q0 + 1) & 7]), "v"(fb[1][(q0 + 2) & 7]), "v"(fb[1][(q0 + 3) & 7]),
+                      "v"(fa[1][(q0 + 0) >> 3]), "v"(fa[1][(q0 + 1) >> 3]), "v"(fa[1][(q0 + 2) >> 3]), "v"(fa[1][(q0 + 3) >> 3]),
+                      "v"(g < 8 ? voff_a_t[g & 7] : voff_w_t[g & 7]), "s"(g < 8 ? a_k : w_k)
+                    : "memory", "scc");
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mma1(1, g * 4 + q);
+            }
+            VC_SW_FENCE();
+        }
+    };
+    for (int kt = 0; kt < nk - 2; ++kt) ktile(kt, std::true_type{});
+    if (nk > 1) ktile(nk - 2, std::false_type{});
+    ktile(nk - 1, std::false_type{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the hand-issued MFMAs' results are read by VALU code below
+#undef VC_SW_FENCE
+
+    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
+    const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
+    const bf16_t* resid = (const bf16_t*)p.resid;
+    const bf16_t* gate = (const bf16_t*)p.gate;
+    const bf16_t* hint = (const bf16_t*)p.hint;
+    bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / rpb;
+        const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wc * 128 + j * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (bias) {
+                float bb[4];
+                unpack4(*(const uint2*)(bias + n), bb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (EPI == VC_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
+            } else if (EPI == VC_EPI_BIAS_RESID) {
+                float r[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+            } else if (EPI == VC_EPI_GELU_MUL) {
+                float r[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
+            } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
+                float r[4], gg[4];
+                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
+                unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), gg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * gg[e]);
+                if (hint) {
+                    float hv[4];
+                    unpack4(*(const uint2*)(hint + (int64_t)m * p.ldh + n), hv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(hv[e] * p.hint_scale);
+                }
+            }
+            if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
+            *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
+        }
+    }
+}
+
+template <int EPI>
+int launch_sw_e(const VcGemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 65536;
     static std::atomic<uint64_t> attr_done{0};
-    if (!vc_set_lds_once(attr_done, (const void*)gemm_bf16_kernel<Cfg, SB>, Cfg::LDS_BYTES)) return VC_E_HIP;
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_sw_kernel<EPI>, LDS)) return VC_E_HIP;
+    const int ng = p.ngroups > 1 ? p.ngroups : 1;
+    const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
+    const int ntiles = nTm * nTn;
+    const int grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(gemm_sw_kernel<EPI>, dim3(grid), dim3(256), LDS, stream, p, nTm, nTn, ntiles);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+int launch_sw(const VcGemmParams& p, hipStream_t stream) {
+    switch (p.epilogue) {
+        case VC_EPI_BIAS: return launch_sw_e<VC_EPI_BIAS>(p, stream);
+        case VC_EPI_BIAS_GELU: return launch_sw_e<VC_EPI_BIAS_GELU>(p, stream);
+        case VC_EPI_BIAS_RESID: return launch_sw_e<VC_EPI_BIAS_RESID>(p, stream);
+        case VC_EPI_BIAS_GATE_RESID: return launch_sw_e<VC_EPI_BIAS_GATE_RESID>(p, stream);
+        case VC_EPI_GELU_MUL: return launch_sw_e<VC_EPI_GELU_MUL>(p, stream);
+    }
+    return VC_E_INVALID;
+}
+
+template <class Cfg, bool SB, int EPI>
+int launch_cfg_e(const VcGemmParams& p, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_bf16_kernel<Cfg, SB, EPI>, Cfg::LDS_BYTES)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + Cfg::BM - 1) / Cfg::BM, nTn = ng * ((p.N + Cfg::BN - 1) / Cfg::BN);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, SB>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, p, nTm, nTn,
+    hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, SB, EPI>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, p, nTm, nTn,
                        ntiles);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+template <class Cfg, bool SB = false>
+int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
+    switch (p.epilogue) {
+        case VC_EPI_BIAS: return launch_cfg_e<Cfg, SB, VC_EPI_BIAS>(p, stream);
+        case VC_EPI_BIAS_GELU: return launch_cfg_e<Cfg, SB, VC_EPI_BIAS_GELU>(p, stream);
+        case VC_EPI_BIAS_RESID: return launch_cfg_e<Cfg, SB, VC_EPI_BIAS_RESID>(p, stream);
+        case VC_EPI_BIAS_GATE_RESID: return launch_cfg_e<Cfg, SB, VC_EPI_BIAS_GATE_RESID>(p, stream);
+        case VC_EPI_GELU_MUL: return launch_cfg_e<Cfg, SB, VC_EPI_GELU_MUL>(p, stream);
+    }
+    return VC_E_INVALID;
 }
 
 }  // namespace
@@ -534,19 +816,20 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (p.ngroups < 0 || p.ngroups > 3) return VC_E_INVALID;
     for (int g = 1; g < p.ngroups; ++g)
         if (!p.Wg[g - 1] || !p.Cg[g - 1]) return VC_E_INVALID;
-    // p.tile (tests / tuning): 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel
+    // p.tile (tests / tuning): 0 auto, 1 -> 128x128, 2 -> 256x256, 3 -> 256x256 with 64-bit DMA addresses, 4 -> ping-pong kernel,
+    // 5 -> one-wave-per-SIMD kernel
     bool big = (p.M >= 1024 && p.N >= 256);
     // small problems (a 1.3B model on a 9-frame clip: M = 3840, N = 1536 -> 90 tiles of 256 x 256 for 256 CUs): 128 x 128 tiles,
     // two workgroups per CU, fill the chip where the big tile leaves two thirds of it idle; same K order, bit-identical results
     const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ngroups > 1 ? p.ngroups : 1);
     if (t256 < VC_GEMM_SMALL_TILES) big = false;
     if (p.tile == 1) big = false;
-    if (p.tile == 2) big = true;
+    if (p.tile == 2 || p.tile == 5) big = true;
     // every tile row readable (M a multiple of 256 or padded buffers), N % 256 == 0, K % 128 == 0: ping-pong kernel
     const bool rows_ok = (p.M % 256 == 0) || p.a_rows_padded;
     if (big && rows_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
-        (p.tile == 0 || p.tile == 4))
-        return launch_pp(p, stream);
+        (p.tile == 0 || p.tile == 4 || p.tile == 5))
+        return p.tile == 5 ? launch_sw(p, stream) : launch_pp(p, stream);
     // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
     if (big && fits32 && p.tile != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);
