@@ -285,7 +285,6 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 // WAR: a half is restaged two phases after its last read.  RAW: the counted vmcnt (all but the two youngest half-tiles)
 // sits before a barrier that every reader passes before its first read of that K-tile, one phase later.
 // Rows past M are read (never stored): the caller guarantees they are readable (a_rows_padded / M % 256 == 0).
-// Past the last K-tile the staging re-reads the last two K-tiles into dead stages (keeps vmcnt counts uniform).
 // The epilogue kind is a template parameter (here and in the other kernels): with all five kinds inline behind run-time
 // branches this kernel was 52 KB of code, most of it unrolled epilogue, against a 64 KB instruction cache shared by two
 // CUs; per kind it is 11-24 KB (round 2: 0-2 % at the cfg-3 shapes, same-box A/B).
@@ -406,12 +405,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     __builtin_amdgcn_sched_barrier(0);
 
     // One pair of K-tiles (8 phases).  Loads issued during the pair fill K-tiles kt+1 (its Ah1), kt+2 and kt+3 (minus its Ah1);
-    // in the LAST pair of the tile what would lie past K-tile nk-1 re-reads the last two K-tiles into dead stages (never read;
-    // keeps the vmcnt counts uniform without a clamp in the hot loop).
+    // the LAST pair of the tile stages nothing past K-tile nk-1 and waits for everything instead of counting.
     auto pair = [&](int kt, auto last_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_c)::value;
         auto stage_ahead = [&](int stage, int region, int off) __attribute__((always_inline)) {
-            stage_half(stage, region, LAST && off >= 2 ? kt + off - 2 : kt + off);
+            if (!(LAST && off >= 2)) stage_half(stage, region, kt + off);
         };
 #pragma unroll
         for (int st = 0; st < 2; ++st) {     // st = 0: K-tile kt (even stage), st = 1: K-tile kt+1 (odd stage)
@@ -434,7 +432,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             read_a(st, 1);
             __builtin_amdgcn_sched_barrier(0);
             stage_ahead(st, 0, 2 + st);                         // Ah0
-            VC_PP_WAIT("s_waitcnt vmcnt(4)");
+            if (!LAST) VC_PP_WAIT("s_waitcnt vmcnt(4)");
+            else if (st == 0) VC_PP_WAIT("s_waitcnt vmcnt(0)");  // nothing younger in flight: the last K-tile has landed
             VC_PP_BARRIER();
             mma(1, 1, st);
             VC_PP_BARRIER();
