@@ -38,6 +38,9 @@ namespace {
 #ifndef VC_ATTN_ROWSUM
 #define VC_ATTN_ROWSUM 0    // measured (round 2, tools/ab_attn.sh): 0: 1144 TF, 1: 1115, 2: 1126, 4: 1116 -- pinning the sums costs
 #endif
+#ifndef VC_ATTN_PACKED
+#define VC_ATTN_PACKED 0    // measured (round 2, tools/ab_attn.sh, same box): 0: 1204 TF, 1 (v_pk_fma_f32 / v_pk_add_f32 pairs): 1140 TF
+#endif
 #ifndef VC_ATTN_ABLATE
 #define VC_ATTN_ABLATE 0
 #endif
@@ -321,6 +324,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
 #pragma unroll
         for (int i = 0; i < NPS; ++i) ps[i] = 0.f;
         bf16x8 pf[4];
+#if VC_ATTN_PACKED
+        // two elements per VALU instruction where the ISA has a packed fp32 form (v_pk_fma_f32, v_pk_add_f32): the scale /
+        // subtract and the row sums take 16 + 16 instructions per tile instead of 32 + 32 on the issue port the MFMAs share;
+        // the row sum becomes two interleaved partial sums (even / odd keys), added once per tile
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
+        f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2_t x = {Sc[s >> 1][8 * (s & 1) + j], Sc[s >> 1][8 * (s & 1) + j + 1]};
+                const f32x2_t y = __builtin_elementwise_fma(x, c2, nmc2);
+                const f32x2_t pe = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+                ps2 += pe;
+                pf[s][j] = (__bf16)pe[0];
+                pf[s][j + 1] = (__bf16)pe[1];
+            }
+        l_run += ps2[0] + ps2[1];
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -339,6 +362,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             for (int i = 1; i < NPS; ++i) tot += ps[i];
             l_run += tot;
         }
+#endif
         if (VC_ATTN_ROWSUM > 0) asm volatile("" : "+v"(l_run));
         // ---- phase 2: MFMA O += V(t)^T.P(t)^T  ||  VALU row maxima of S(t+1) ----
         const char* vbuf = smem + P_VST + PAR * TILE_BYTES;
