@@ -14,7 +14,7 @@ from versecrafter_amd import ops
 tiles = [int(t) for t in sys.argv[1:]] or [4, 5]
 M, N = 65536, 5120
 g = torch.Generator(device="cuda").manual_seed(0)
-ks = (1024, 2048, 4096, 8192, 16384)
+ks = tuple(int(k) for k in os.environ.get("KS", "1024,2048,4096,8192,16384").split(","))
 res = {t: [] for t in tiles}
 for K in ks:
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()

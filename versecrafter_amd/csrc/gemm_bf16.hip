@@ -26,6 +26,13 @@
 #define VC_GEMM_SMALL_TILES 256     // fewer 256 x 256 tiles than CUs: the 128 x 128 kernel is used (see vc_launch_gemm)
 #endif
 
+#ifdef VC_PP_TRACE
+__device__ uint64_t* vc_pp_trace_buf = nullptr;
+extern "C" int vc_debug_set_gemm_trace(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(vc_pp_trace_buf), &buf, sizeof buf) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -310,6 +317,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+#ifdef VC_PP_TRACE      // tools/trace_gemm.py: per-workgroup timestamps (100 MHz) of entry / first MFMA / loop end / stores issued
+    auto now = [] { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
+    uint64_t* trc = vc_pp_trace_buf ? vc_pp_trace_buf + (size_t)blockIdx.x * 8 : nullptr;
+    if (trc && tid == 0) {
+        trc[0] = now();
+        trc[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_ID
+        trc[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));      // XCC_ID
+        trc[6] = id;
+    }
+#endif
 
     auto uniform_ptr = [](const char* q) {     // force a wave-uniform address into an SGPR pair
         const uint64_t u = (uint64_t)q;
@@ -446,12 +463,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             VC_PP_BARRIER();
         }
     };
+#ifdef VC_PP_TRACE
+    if (trc && tid == 0) trc[1] = now();
+#endif
     for (int kt = 0; kt < nk - 2; kt += 2) pair(kt, std::false_type{});
     pair(nk - 2, std::true_type{});
     if (wr == 0) VC_PP_BARRIER();          // equalise the barrier count
     VC_PP_WAIT("s_waitcnt vmcnt(0)");      // nothing may still be landing in LDS when the workgroup retires
 #undef VC_PP_BARRIER
 #undef VC_PP_WAIT
+#ifdef VC_PP_TRACE
+    if (trc && tid == 0) trc[2] = now();
+#endif
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
     // (kept inline in both kernels on purpose: factored into one shared device function it compiled 1-2 % slower)
@@ -507,6 +530,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
         }
     }
+#ifdef VC_PP_TRACE
+    if (trc && tid == 0) {
+        trc[3] = now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trc[7] = now();                                            // this wave's stores acknowledged
+    }
+#endif
 }
 
 template <int EPI>
