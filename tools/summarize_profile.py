@@ -18,7 +18,7 @@ def find(d, suffix):
 
 
 def short(name):
-    for k in ("attn_fwd_pipe_kernel", "attn_short_kernel", "attn_fwd_kernel", "conv_igemm_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "t5_attention_kernel", "geoada_context_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
+    for k in ("attn_fwd_pipe_kernel", "attn_short_kernel", "qkv_front_kernel", "gemm_sw_kernel", "attn_fwd_kernel", "conv_igemm_kernel", "gemm_pp_kernel", "gemm_bf16_kernel", "t5_attention_kernel", "geoada_context_kernel", "layernorm_kernel", "rmsnorm_rope_kernel", "patchify_kernel",
               "unpatchify_kernel", "small_linear_kernel", "modulation_kernel", "axpy_kernel", "copy_strided_kernel"):
         if k in name:
             if k == "gemm_bf16_kernel":
@@ -43,7 +43,7 @@ def main():
         e[3].append(r)
     for k, e in sorted(fam.items(), key=lambda kv: -kv[1][1])[:12]:
         print(f"{k:45s} {e[0]:7d} {e[1] / 1e6:11.2f} {e[1] / e[0] / 1e3:11.1f} {e[2]:7.2f}")
-        if len(e[3]) > 1:
+        if len(e[3]) > 1 and k == "gemm_pp_kernel":      # the epilogue kinds of the production GEMM
             for r in e[3]:
                 m = re.search(r"_kernel<([^>]*)>", r["Name"])
                 print(f"{'    <' + (m.group(1) if m else '?') + '>':45s} {int(r['Calls']):7d} {int(r['TotalDurationNs']) / 1e6:11.2f} "
