@@ -484,6 +484,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     const bf16_t* hint = (const bf16_t*)p.hint;
     bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+    const bool wide = (p.ldc & 7) == 0 && ((uintptr_t)C & 15) == 0;      // rows of C 16-byte aligned
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -491,7 +492,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
         const int b = m / rpb;
         const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int jp = 0; jp < 2; ++jp) {
+        uint2 pk[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = jp * 2 + jj;
             const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (bias) {
@@ -527,7 +532,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                 }
             }
             if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
-            *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
+            pk[jj] = pack4(v);
+        }
+        // two neighbouring 16-column blocks -> 16-byte stores: the lane groups (rows of 16 lanes) g and g^1 trade halves so that
+        // even groups hold 8 consecutive columns of block 2jp, odd groups of block 2jp+1 (v_permlane16_swap: odd rows of the
+        // first operand <-> even rows of the second); a store then covers 64 contiguous bytes per row instead of 32
+        if (wide) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+            const int g = lane >> 4;
+            const int n = n0 + wc * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
+            *(uint4*)(C + (int64_t)m * p.ldc + n) = uint4{s0[0], s1[0], s0[1], s1[1]};
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                *(uint2*)(C + (int64_t)m * p.ldc + n0 + wc * 64 + (jp * 2 + jj) * 16 + (lane >> 4) * 4) = pk[jj];
+        }
         }
     }
 #ifdef VC_PP_TRACE
