@@ -122,6 +122,8 @@ def parse_args(argv=None):
     ap.add_argument("--num_inference_steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cfg-degree", type=int, default=int(os.environ.get("VC_BENCH_CFG_DEGREE", "0")), choices=(0, 1, 2),
+                    help="ranks that split the CFG pair (0 = auto: 2 when --gpus 2, else 1)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl (= RCCL; product: the engine's own communicators over xGMI) or gloo: a REHEARSAL of the N > 1 "
                          "launch on a box with fewer GPUs than ranks -- ranks share devices round-robin, exchange buffers are "
@@ -234,10 +236,19 @@ def run_rank(args):
     torch.manual_seed(0)
     model = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16, **mk)
     model.init_weights(zero_init_outputs=False)
+    # N = 2: the two samples of the CFG pair are independent units -- one per rank, no data-path collective, only the noise
+    # prediction is all-gathered.  N >= 4: Ulysses over all ranks.  --cfg-degree overrides.
+    cfg_degree = args.cfg_degree if args.cfg_degree else (2 if world == 2 else 1)
+    if world % cfg_degree:
+        raise SystemExit(f"--cfg-degree {cfg_degree} does not divide --gpus {world}")
+    sp_degree = world // cfg_degree
     if use_dist:
         from versecrafter_amd import dist as vdist
-        vdist._SP_GROUP = dist.group.WORLD
-        model.enable_multi_gpus_inference(vdist.SequenceParallel(dist.group.WORLD, force_exchange=(world == 1)))
+        sp_group, bp_group = vdist.make_groups(sp_degree, cfg_degree)
+        if sp_degree == 1 and cfg_degree > 1:
+            model.enable_multi_gpus_inference()                       # batch-parallel only
+        else:
+            model.enable_multi_gpus_inference(vdist.SequenceParallel(sp_group, force_exchange=(world == 1)))
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
     pipe = WanVerseCrafterPipeline(transformer=model, scheduler=scheduler)
     pipe._guidance_scale = 5.0
@@ -306,6 +317,8 @@ def run_rank(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     rccl_ranks = model.sp_comm_ranks()
+    if cfg_degree > 1 and not rehearsal:
+        rccl_ranks = max(rccl_ranks, 1) * cfg_degree      # + the batch-parallel gather on torch's nccl (= RCCL) groups
 
     if rank == 0:
         NL, NA = mk["num_layers"], (mk["num_layers"] + 1) // 2
@@ -319,7 +332,9 @@ def run_rank(args):
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights seed 0, inputs seed 2025)",
             "config": {"workload": args.workload, "latent": [16, T, h, w], "tokens": L, "global_batch": 2,
                        "cfg": "batched pair", "guidance_scale": 5.0, "sampler": "UniPC shift 16",
-                       "teacache": "off", "parallelism": f"ulysses-sp{world}", "pflop_per_step": f_step / 1e15},
+                       "teacache": "off",
+                       "parallelism": f"ulysses-sp{world}" if cfg_degree == 1 else f"cfg{cfg_degree} x ulysses-sp{sp_degree}",
+                       "pflop_per_step": f_step / 1e15},
             "step_mfma_frac": f_step * sps / (world * PEAK_BF16_TFLOPS * 1e12),
             # the same with the output-neutral work the engine skips taken out of the numerator (see skipped_flops)
             "step_mfma_frac_executed": (f_step - skipped_flops(mk["dim"], NL, NA, L, 2, (n_un, n_co), mk.get("text_len", 512),
@@ -329,6 +344,8 @@ def run_rank(args):
             "rccl_ranks": rccl_ranks,
             "transport": ("none (single rank)" if not use_dist else
                           "gloo + host-staged buffers (REHEARSAL of the launch, not a result)" if rehearsal else
+                          "one CFG sample per rank, no data-path collective; the noise prediction is all-gathered over "
+                          "torch.distributed's RCCL group" if sp_degree == 1 else
                           "engine-owned RCCL communicators, one per stream lane" if rccl_ranks else
                           "torch.distributed RCCL process groups, one per stream lane (engine-owned communicators unavailable)"),
         }

@@ -48,7 +48,8 @@ def test_self_launch_two_ranks_rehearsal_on_one_gpu():
     """Two rank processes on this box's one GPU (RCCL refuses two ranks per device, so the rehearsal backend is gloo with
     host-staged exchange buffers): rendezvous, sequence-parallel engine in both ranks, barrier + max-over-ranks timing, ONE
     JSON line with n_gpus == 2 on the parent's stdout."""
-    r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"])
+    r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
+              "--cfg-degree", "1"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -57,6 +58,18 @@ def test_self_launch_two_ranks_rehearsal_on_one_gpu():
     assert out["config"]["parallelism"] == "ulysses-sp2" and out["scaling"] == "strong"
     assert out["outputs_finite"] is True and out["value"] > 0
     assert out["rccl_ranks"] == 0 and "REHEARSAL" in out["transport"]
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_default_is_one_cfg_sample_per_rank():
+    """--gpus 2 without --cfg-degree: the CFG pair is split across the two ranks (no sequence exchange), outputs gathered."""
+    r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "cfg2 x ulysses-sp1"
+    assert out["outputs_finite"] is True and out["value"] > 0 and "REHEARSAL" in out["transport"]
 
 
 @pytest.mark.gpu

@@ -103,3 +103,85 @@ def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide, world, lanes):
         assert err is None, (rank, err)
         assert ok, f"rank {rank}: max diff {diff}"
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _worker_cfg(rank, world, port, sp_degree, q, teacache_cfg_skip):
+    """One sample of the CFG pair per rank (dist.set_multi_gpus_devices cfg_degree = 2), Ulysses of degree sp_degree inside
+    each sample's group; the per-rank outputs are gathered back into the [uncond, cond] batch."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from oracle import wan_oracle as O
+    from versecrafter_amd import dist as vdist
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vdist.set_multi_gpus_devices(sp_degree, 1, cfg_degree=2)
+        cfg = O.Config(**TINY)
+        W = O.random_weights(cfg, 11)
+        g = torch.Generator().manual_seed(1)
+        T, h, w = 3, 8, 12
+        x1 = torch.randn(1, 16, T, h, w, generator=g).bfloat16().cuda()
+        geo1 = torch.randn(1, 128, T, h, w, generator=g).bfloat16().cuda()
+        x, geo = torch.cat([x1, x1]), torch.cat([geo1, geo1])                   # the sampler's CFG pair (PIPE.py:878-887)
+        ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+        steps = 8 if teacache_cfg_skip else 2
+        ts = [torch.tensor([900.0 - 60 * i] * 2).cuda() for i in range(steps)]
+
+        def make():
+            m = VerseCrafterWanTransformer3DModel(**TINY)
+            m.load_state_dict(W)
+            m = m.to(torch.bfloat16).to("cuda")
+            if teacache_cfg_skip:       # residual re-use on some steps, conditional sample only on the last 3 of 8
+                m.enable_teacache([1.0, 0.0], steps, 0.5, num_skip_start_steps=2)
+                m.enable_cfg_skip(0.4, steps)
+            return m
+
+        def run(m):
+            outs = []
+            for i, t in enumerate(ts):
+                m.num_inference_steps, m.current_steps = steps, i
+                outs.append(m(x, t, geo, ctx, 72))
+            torch.cuda.synchronize()
+            return outs
+
+        ref = run(make())                                                       # both samples on this rank, no groups
+        m = make()
+        m.enable_multi_gpus_inference()
+        assert m._bp is not None and m._bp.world_size == 2 and m._bp.rank == rank // sp_degree
+        assert m.sp_world_size == sp_degree
+        got = run(m)
+        ok = all(torch.equal(a, b) for a, b in zip(got, ref))
+        diff = max((a.float() - b.float()).abs().max().item() for a, b in zip(got, ref))
+        q.put((rank, ok, diff, None))
+    except Exception as e:
+        q.put((rank, False, float("nan"), repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sp_degree,teacache_cfg_skip", [(2, 1, False), (2, 1, True), (4, 2, False)])
+def test_cfg_pair_across_ranks_equals_batched_pair_bitwise(world, sp_degree, teacache_cfg_skip):
+    """cfg_degree = 2: rank groups take one sample of the [uncond, cond] pair each (no exchange between the groups), the
+    outputs are all-gathered; every rank must see the batched single-process result bit for bit -- also across TeaCache
+    re-use steps and the switch to conditional-only steps (cfg_skip: the cond rank works, the other one receives), and with a
+    2-way Ulysses exchange inside each sample's group (4 processes)."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker_cfg, args=(r, world, port, sp_degree, q, teacache_cfg_skip)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=300) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, ok, diff, err in res:
+        assert err is None, (rank, err)
+        assert ok, f"rank {rank}: max diff {diff}"
+    assert all(p.exitcode == 0 for p in procs)

@@ -23,23 +23,34 @@ import torch.distributed as dist
 from . import _lib
 
 _SP_GROUP = None
+_BP_GROUP = None       # batch-parallel group (the samples of a CFG pair on different ranks); None = off
+_SP_DEGREE = 1
 
 
-def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int):
+def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1):
     """CLI.py:180.  One process per GPU (torchrun env); returns this rank's device.  The reference's
-    ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring (head counts divide)."""
-    global _SP_GROUP
+    ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring (head counts divide).
+
+    cfg_degree (this build; the reference has no such split): the samples of one forward's batch -- the [uncond, cond] pair of
+    classifier-free guidance, PIPE.py:878-887 -- are independent units, so `cfg_degree` ranks can take one sample each with no
+    data-path collective at all; only the noise prediction (4 MB at cfg-3) is all-gathered after the forward.  World size =
+    cfg_degree * ulysses_degree * ring_degree; rank r works on sample r // S inside the Ulysses group of its S = ulysses * ring
+    neighbours [r - r % S, r - r % S + S)."""
+    global _SP_GROUP, _BP_GROUP, _SP_DEGREE
     degree = int(ulysses_degree) * int(ring_degree)
-    if degree > 1:
+    cfg_degree = int(cfg_degree)
+    world = degree * cfg_degree
+    _SP_DEGREE = degree
+    if world > 1:
         if not dist.is_initialized():
             # host-side gloo for rendezvous / object broadcast (the ncclUniqueIds of the engine's communicators), torch's
             # "nccl" (= RCCL) registered for device tensors; the engine's exchanges never go through torch
             dist.init_process_group("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
-        if dist.get_world_size() != degree:
-            raise ValueError(f"ulysses_degree*ring_degree = {degree} but world size is {dist.get_world_size()}")
+        if dist.get_world_size() != world:
+            raise ValueError(f"cfg_degree*ulysses_degree*ring_degree = {world} but world size is {dist.get_world_size()}")
         if int(ring_degree) > 1 and dist.get_rank() == 0:
             print(f"[versecrafter_amd] ring_degree={ring_degree} folded into a pure Ulysses degree of {degree}")
-        _SP_GROUP = dist.group.WORLD
+        make_groups(degree, cfg_degree)
     local = int(os.environ.get("LOCAL_RANK", 0))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
@@ -47,8 +58,73 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int):
     return torch.device("cpu")
 
 
+def make_groups(sp_degree: int, cfg_degree: int = 1):
+    """The process groups of set_multi_gpus_devices on an initialised world of cfg_degree * sp_degree ranks (callers that pick
+    their own devices: bench.py's one-GPU rehearsal).  Returns (sp_group or None, bp_group or None)."""
+    global _SP_GROUP, _BP_GROUP, _SP_DEGREE
+    world = dist.get_world_size()
+    if world != sp_degree * cfg_degree:
+        raise ValueError(f"cfg_degree*sp_degree = {sp_degree * cfg_degree} but world size is {world}")
+    _SP_DEGREE = sp_degree
+    _SP_GROUP = _BP_GROUP = None
+    if cfg_degree == 1:
+        _SP_GROUP = dist.group.WORLD
+        return _SP_GROUP, None
+    me = dist.get_rank()
+    for c in range(cfg_degree):                   # every rank creates every group (new_group is collective)
+        ranks = list(range(c * sp_degree, (c + 1) * sp_degree))
+        g = dist.new_group(ranks=ranks) if sp_degree > 1 else None
+        if me in ranks:
+            _SP_GROUP = g
+    for s_ in range(sp_degree):
+        ranks = list(range(s_, world, sp_degree))
+        g = dist.new_group(ranks=ranks)
+        if me in ranks:
+            _BP_GROUP = g
+    return _SP_GROUP, _BP_GROUP
+
+
 def get_sp_group():
     return _SP_GROUP
+
+
+def get_bp_group():
+    return _BP_GROUP
+
+
+class BatchParallel:
+    """The samples of one forward's batch on different ranks (see set_multi_gpus_devices: cfg_degree).  Nothing of the forward
+    itself is exchanged; `gather` puts the per-rank outputs back together, `broadcast` hands one rank's output to the group
+    (steps on which only the conditional sample is computed, cfg_skip).  gloo groups (tests) stage device tensors through host."""
+
+    def __init__(self, group):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def gather(self, x: torch.Tensor) -> torch.Tensor:
+        """x [1, ...] of this rank's sample -> [world_size, ...] in rank order."""
+        x = x.contiguous()
+        if _host_bounce(x, self.group):
+            h = x.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world_size)]
+            dist.all_gather(parts, h, group=self.group)
+            return torch.cat(parts, dim=0).to(x.device)
+        out = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
+    def broadcast(self, x: torch.Tensor, src: int) -> torch.Tensor:
+        """x from group rank `src` to everyone (in place on the other ranks)."""
+        g_src = dist.get_global_rank(self.group, src)
+        if _host_bounce(x, self.group):
+            h = x.cpu()
+            dist.broadcast(h, src=g_src, group=self.group)
+            if self.rank != src:
+                x.copy_(h)
+            return x
+        dist.broadcast(x, src=g_src, group=self.group)
+        return x
 
 
 def get_sequence_parallel_world_size():
@@ -163,7 +239,7 @@ class SequenceParallel:
 
     def __init__(self, group=None, transport=None, force_exchange=False):
         self.group = group if group is not None else get_sp_group()
-        if self.group is None and dist.is_initialized():
+        if self.group is None and dist.is_initialized() and _BP_GROUP is None:
             self.group = dist.group.WORLD
         self.world_size = 1 if self.group is None else dist.get_world_size(self.group)
         self.rank = 0 if self.group is None else dist.get_rank(self.group)

@@ -169,6 +169,7 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         self.sp_world_rank = 0
         self.should_calc = True
         self._sp = None
+        self._bp = None             # dist.BatchParallel: one sample of the batch per rank
         self._engine = None
         self._loaded = {}           # key -> (data_ptr, version)
         self._rope_dirty = True
@@ -318,11 +319,20 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
                                 rope_params(1024, 2 * (self.d // 6))], dim=1)
         self._rope_dirty = True
 
-    def enable_multi_gpus_inference(self, sp_group=None):
+    def enable_multi_gpus_inference(self, sp_group=None, batch_group=None):
         """WT.py:901-921: switch self-attention of blocks and geoada_blocks to the Ulysses exchange.
         `sp_group`: a torch.distributed group (default: the one set_multi_gpus_devices made), or an object with
-        the SequenceParallel interface (world_size, rank, c_all_to_all, c_all_gather) -- tests inject one."""
+        the SequenceParallel interface (world_size, rank, c_all_to_all, c_all_gather) -- tests inject one.
+        `batch_group` (default: the one set_multi_gpus_devices(cfg_degree=...) made, if any): the samples of a forward's batch go
+        to different ranks of this group (dist.BatchParallel); the Ulysses exchange then runs inside each sample's own group."""
         from .. import dist as vdist
+        if batch_group is None:
+            batch_group = vdist.get_bp_group()
+        self._bp = None
+        if batch_group is not None:
+            self._bp = batch_group if hasattr(batch_group, "world_size") else vdist.BatchParallel(batch_group)   # a raw process group has gather() too
+        if self._bp is not None and sp_group is None and vdist.get_sp_group() is None:
+            return                              # one rank per sample: no sequence exchange at all
         custom = hasattr(sp_group, "c_all_to_all") or hasattr(sp_group, "attach")
         self._sp = sp_group if custom else vdist.SequenceParallel(sp_group)
         self.sp_world_size = self._sp.world_size
@@ -481,9 +491,25 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         B, Cin, T, H, W = x.shape
         if Cin != self.in_dim or tuple(geoada_context.shape[2:]) != (T, H, W) or geoada_context.shape[0] != B:
             raise ValueError(f"shape mismatch: x {tuple(x.shape)} geoada_context {tuple(geoada_context.shape)}")
+        # batch-parallel ranks (dist.set_multi_gpus_devices cfg_degree): sample r of the batch is this rank's; on steps that
+        # compute the conditional sample only (cfg_skip) the last rank of the group -- the one that has been computing that
+        # sample, so its TeaCache residual is the right one (VC.py:396 previous_residual[-B:]) -- works for everybody
+        bp, bp_mode = getattr(self, "_bp", None), None
+        if bp is not None and bp.world_size > 1:
+            if B == bp.world_size:
+                bp_mode, r = "split", bp.rank
+                x, t, geoada_context, context = x[r:r + 1], t[r:r + 1], geoada_context[r:r + 1], list(context)[r:r + 1]
+                B = 1
+            elif B == 1:
+                bp_mode = "owner" if bp.rank == bp.world_size - 1 else "idle"
+            else:
+                raise ValueError(f"batch of {B} samples on a batch-parallel group of {bp.world_size} ranks")
         lib = _lib.load()
-        self.prepare_video(geoada_context, context, seq_len)
-        h = self._engine
+        if bp_mode != "idle":
+            self.prepare_video(geoada_context, context, seq_len)
+        else:
+            self._sync_engine(x.device)               # weights only (the TeaCache gate below evaluates the time embedding)
+        h = self._engine_handle()
         tf = t.to(device=x.device, dtype=torch.float32).contiguous()
         if tf.dim() != 1 or tf.shape[0] != B:
             raise ValueError("t must have shape [B]")
@@ -513,13 +539,18 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
                 flags |= _lib.VC_FWD_SHARED_CFG_INPUT
         self._last_flags = flags                 # introspection for tests
         out = torch.empty(B, self.out_dim, T, H, W, dtype=torch.bfloat16, device=x.device)
-        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        with torch.cuda.device(x.device):
-            rc = lib.vc_forward(h, C.c_void_p(xc.data_ptr()), C.c_void_p(tf.data_ptr()), C.c_void_p(out.data_ptr()),
-                                float(geoada_context_scale), flags, stream)
-        if rc != 0 and self._sp is not None and getattr(self._sp, "error", None) is not None:
-            raise RuntimeError("sequence-parallel collective failed inside vc_forward") from self._sp.error
-        _lib.check(rc, h)
+        if bp_mode != "idle":
+            stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            with torch.cuda.device(x.device):
+                rc = lib.vc_forward(h, C.c_void_p(xc.data_ptr()), C.c_void_p(tf.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    float(geoada_context_scale), flags, stream)
+            if rc != 0 and self._sp is not None and getattr(self._sp, "error", None) is not None:
+                raise RuntimeError("sequence-parallel collective failed inside vc_forward") from self._sp.error
+            _lib.check(rc, h)
+        if bp_mode == "split":
+            out = bp.gather(out)
+        elif bp_mode in ("owner", "idle"):
+            out = bp.broadcast(out, bp.world_size - 1)
         if self.teacache is not None and cond_flag:                                # VC.py:438-441
             self.teacache.cnt += 1
             if self.teacache.cnt == self.teacache.num_steps:
