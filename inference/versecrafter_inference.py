@@ -49,6 +49,9 @@ def parse_args(argv=None):
     p.add_argument("--sample_size", type=str, default="720,1280")
     p.add_argument("--ulysses_degree", type=int, default=2)
     p.add_argument("--ring_degree", type=int, default=2)
+    p.add_argument("--cfg_degree", type=int, default=1, choices=(1, 2),
+                   help="(this build) ranks that split the classifier-free-guidance pair: world = cfg_degree * ulysses_degree * "
+                        "ring_degree; with 2 GPUs, `--cfg_degree 2 --ulysses_degree 1 --ring_degree 1` needs no sequence exchange")
     p.add_argument("--guidance_scale", type=float, default=5.0)
     p.add_argument("--seed", type=int, default=2025)
     p.add_argument("--fps", type=int, default=16)
@@ -89,7 +92,7 @@ def parse_args(argv=None):
 def main(argv=None):
     args = parse_args(argv)
     height, width = [int(x) for x in args.sample_size.split(",")]
-    device = set_multi_gpus_devices(args.ulysses_degree, args.ring_degree)
+    device = set_multi_gpus_devices(args.ulysses_degree, args.ring_degree, cfg_degree=args.cfg_degree)
     if device.type != "cuda":
         raise SystemExit("versecrafter_amd needs an MI355X (HIP) device: there is no CPU path")
     weight_dtype = torch.bfloat16
@@ -136,7 +139,7 @@ def main(argv=None):
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)  # CLI.py:252-261
     pipeline = WanVerseCrafterPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae,
                                        transformer=transformer, scheduler=scheduler)
-    if args.ulysses_degree * args.ring_degree > 1:
+    if args.ulysses_degree * args.ring_degree * args.cfg_degree > 1:
         transformer.enable_multi_gpus_inference()                                   # CLI.py:271-273
     pipeline.to(device)
     if args.enable_teacache:                                                        # CLI.py:305-313

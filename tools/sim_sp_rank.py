@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--gbps", type=float, default=None, help="egress GB/s of this rank during an exchange; 0 = no wire time")
     ap.add_argument("--dual", type=int, default=None, help="force the two-chain schedule on (1) / off (0)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--batch", type=int, default=2, choices=(1, 2),
+                    help="samples on this rank: 2 = the CFG pair (Ulysses over all ranks), 1 = one sample (cfg_degree 2: an "
+                         "N-GPU run is then two groups of P = N/2)")
     args = ap.parse_args()
     P = args.P
     gbps = args.gbps if args.gbps is not None else max(1, P - 1) * 153.0 * 0.8
@@ -61,25 +64,29 @@ def main():
     geo = torch.randn(1, 128, T, h, w, generator=g).to(dev, torch.bfloat16).repeat(2, 1, 1, 1, 1)
     ctx = [torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16)]
     t = torch.tensor([900.0, 900.0], device=dev)
+    if args.batch == 1:
+        x, geo, ctx, t = x[1:], geo[1:], ctx[1:], t[1:]
     L = T * (h // 2) * (w // 2)
     model(x, t, geo, ctx, L)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.assert_cfg_pair(x)
+        if args.batch == 2:
+            model.assert_cfg_pair(x)
         model(x, t, geo, ctx, L)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     model.profile_enable(True)
-    model.assert_cfg_pair(x)
+    if args.batch == 2:
+        model.assert_cfg_pair(x)
     model(x, t, geo, ctx, L)
     torch.cuda.synchronize()
     prof = model.profile_read()
     # bytes leaving the rank per step: 60 blocks x (q|k|v + o) x (P-1)/P of [B*L/P, d] bf16
     Lloc = (L + P - 1) // P
-    egress = 60 * 4 * 2 * Lloc * 5120 * 2 * (P - 1) / P if P > 1 else 0.0
+    egress = 60 * 4 * args.batch * Lloc * 5120 * 2 * (P - 1) / P if P > 1 else 0.0
     wire_ms = egress / (gbps * 1e9) * 1e3 if gbps > 0 and P > 1 else 0.0
-    out = {"P": P, "ms_per_forward": dt * 1e3, "ideal_steps_per_s_at_N": 1 / dt, "egress_GB_per_step": egress / 1e9,
+    out = {"P": P, "batch": args.batch, "ms_per_forward": dt * 1e3, "ideal_steps_per_s_at_N": 1 / dt, "egress_GB_per_step": egress / 1e9,
            "egress_gbps": gbps, "injected_wire_ms_per_step": wire_ms, "dual_lane": os.environ.get("VC_DUAL_LANE", "auto"),
            "classes": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] / 1e3) / 1e12 if v["flops"] and v["ms"] else None}
                        for k, v in prof.items() if v["launches"]}}
