@@ -176,7 +176,7 @@ int vc_op_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w, fl
                        const int32_t* grid5, void* stream);
 
 /* Self-attention front (WT.py:385-392) in one pass over qkv [rows][3 dim]: WanRMSNorm + rope_apply of q and k, in place
- * (send == NULL), or q, k (normed, rotated) and v written into the Ulysses exchange layout send[P][3][rows][dim / P]. */
+ * (send == NULL), or q, k (normed, rotated) and v written into the Ulysses exchange layout send[3][B][P][Lloc][dim / P] (rows = B * Lloc, Lloc = grid rows_per_batch). */
 int vc_op_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const void* table,
                     const int32_t* grid5, void* send, int P, void* stream);
 

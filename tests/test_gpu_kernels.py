@@ -347,7 +347,7 @@ def test_rmsnorm_rope(ops, dim, heads):
 @pytest.mark.parametrize("dim,P", [(256, 1), (512, 2), (1536, 3), (5120, 8)])
 def test_qkv_front_equals_separate_norm_rope_and_pack_bitwise(ops, dim, P):
     """The one-pass self-attention front (RMSNorm + RoPE of q and k, optionally packed with v into the Ulysses exchange layout
-    [P][3][rows][dim/P]) against the separate kernels it replaces: rmsnorm_rope on q, on k, then the layout contract of
+    [3][B][P][Lloc][dim/P]) against the separate kernels it replaces: rmsnorm_rope on q, on k, then the layout contract of
     versecrafter_amd.dist.pack_qkv -- bit for bit, incl. a sequence-parallel token offset and padded (un-rotated) rows."""
     from versecrafter_amd.dist import pack_qkv
     rs = np.random.RandomState(dim + P)
@@ -361,7 +361,7 @@ def test_qkv_front_equals_separate_norm_rope_and_pack_bitwise(ops, dim, P):
     got = ops.qkv_front(qkv.clone(), wq, wk, tab, grid, token_offset=off, rows_per_batch=Lr)
     assert torch.equal(got, want)
     send = ops.qkv_front(qkv.clone(), wq, wk, tab, grid, token_offset=off, rows_per_batch=Lr, P=P, pack=True)
-    ref = pack_qkv(want.view(B, Lr, 3, dim // 128, 128), P)    # [P, 3, B, Lr, N/P, 128]
+    ref = pack_qkv(want.view(B, Lr, 3, dim // 128, 128), P)    # [3, B, P, Lr, N/P, 128]
     assert torch.equal(send.view(-1), ref.reshape(-1))
 
 

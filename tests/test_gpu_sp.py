@@ -155,9 +155,10 @@ def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch)
     torch.cuda.synchronize()
     for r in range(P):
         assert errs[r] is None, (r, errs[r], sps[r].error)
-        # two exchanges per self-attention launch; 4 main + 2 adapter blocks.  Sample lanes: block 0 of both chains runs
-        # batched, the other four blocks once per sample
-        assert sps[r].calls == (2 * 2 + 2 * 2 * 4 if lanes in (None, "2", "3") else 2 * 6)
+        # per self-attention launch over Bs samples: 3 Bs all-to-alls for q|k|v (one per tensor and sample) + Bs for o.
+        # 4 main + 2 adapter blocks; block 0 of both chains runs once for the shared prefix of a CFG pair (Bs = 1), else
+        # batched (Bs = 2); the other four blocks cover both samples (batched or one launch per sample: 2 sample-launches each)
+        assert sps[r].calls == 2 * 4 * (1 if cfg_pair else 2) + 4 * 4 * 2
         assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
 
 

@@ -86,9 +86,9 @@ def test_layout_contract_roundtrip():
     from versecrafter_amd import dist as vdist
     P, B, Lloc, N, D = 2, 2, 5, 4, 128
     full = torch.randn(B, P * Lloc, 3, N, D)
-    sends = [vdist.pack_qkv(full[:, r * Lloc:(r + 1) * Lloc], P) for r in range(P)]
+    sends = [vdist.pack_qkv(full[:, r * Lloc:(r + 1) * Lloc], P) for r in range(P)]   # [3, B, P_dst, Lloc, Nl, D] each
     for dst in range(P):
-        recv = torch.stack([sends[src][dst] for src in range(P)])          # all_to_all: slice dst of every src
+        recv = torch.stack([sends[src][:, :, dst] for src in range(P)], dim=2)   # per (tensor, sample) slab: piece dst of every src
         q, k, v = vdist.unpack_tokens(recv)
         Nl = N // P
         assert torch.equal(q, full[:, :, 0, dst * Nl:(dst + 1) * Nl])
@@ -96,7 +96,7 @@ def test_layout_contract_roundtrip():
     o = torch.randn(P, B, P * Lloc, N // P, D)                             # per head-group rank, all tokens
     sends2 = [vdist.pack_out(o[r], P) for r in range(P)]
     for dst in range(P):
-        recv2 = torch.stack([sends2[src][dst] for src in range(P)])
+        recv2 = torch.stack([sends2[src][:, dst] for src in range(P)], dim=1)   # per sample slab
         loc = vdist.unpack_heads(recv2)                                    # [B, Lloc, N, D] of token chunk dst
         want = torch.cat([o[src][:, dst * Lloc:(dst + 1) * Lloc] for src in range(P)], dim=2)
         assert torch.equal(loc, want)

@@ -315,21 +315,26 @@ int time_embed(vc_engine* h, const float* t, int B, float* f_sin, float* f_h, fl
 
 // one all-to-all / all-gather of the Ulysses exchange on the chain's own stream: the chain's own RCCL communicator, or the
 // host callbacks when the caller brought its own transport (vc_sp_init)
-int sp_all_to_all(vc_engine* h, const Lane& lane, const void* send, void* recv, int64_t bytes_per_peer, const char* what) {
+// nslab all-to-alls of equal shape on consecutive slabs of [P][bytes_per_peer] (one RCCL group = one fused launch)
+int sp_all_to_all(vc_engine* h, const Lane& lane, const void* send, void* recv, int64_t bytes_per_peer, const char* what,
+                  int nslab = 1) {
     Lane ln = lane;
     if (lane.comm) ln.s = lane.comm;          // the lane's exchange stream
     if (h->comm[ln.idx]) {
-        if (vc_comm_all_to_all(h->comm[ln.idx], send, recv, bytes_per_peer, ln.s) != VC_OK)
+        if (vc_comm_all_to_all_n(h->comm[ln.idx], send, recv, bytes_per_peer, nslab, ln.s) != VC_OK)
             return fail(h, VC_E_HIP, "all_to_all (%s): %s", what, vc_comm_error());
         return VC_OK;
     }
     if (h->sim_gbps > 0) {            // timing model only: the data stay local, the stream is held for the wire time
-        HIPCHK(h, hipMemcpyAsync(recv, send, (size_t)bytes_per_peer * h->P, hipMemcpyDeviceToDevice, ln.s));
-        VCCHK(h, vc_launch_delay((double)bytes_per_peer * (h->P - 1) / (h->sim_gbps * 1e3), ln.s));
+        HIPCHK(h, hipMemcpyAsync(recv, send, (size_t)bytes_per_peer * h->P * nslab, hipMemcpyDeviceToDevice, ln.s));
+        VCCHK(h, vc_launch_delay((double)bytes_per_peer * nslab * (h->P - 1) / (h->sim_gbps * 1e3), ln.s));
         return VC_OK;
     }
-    if (!h->a2a || h->a2a(h->cb_ctx, send, recv, bytes_per_peer, (void*)ln.s) != 0)
-        return fail(h, VC_E_STATE, "all_to_all callback failed (%s)", what);
+    for (int j = 0; j < nslab; ++j) {
+        const int64_t off = (int64_t)j * h->P * bytes_per_peer;
+        if (!h->a2a || h->a2a(h->cb_ctx, (const char*)send + off, (char*)recv + off, bytes_per_peer, (void*)ln.s) != 0)
+            return fail(h, VC_E_STATE, "all_to_all callback failed (%s)", what);
+    }
     return VC_OK;
 }
 int sp_all_gather(vc_engine* h, const Lane& lane, const void* send, void* recv, int64_t bytes) {
@@ -373,10 +378,12 @@ int from_comm(vc_engine* h, Lane& ln, int k) {
 int sa_pre(vc_engine* h, Lane& ln, int B) {
     if (!h->sp_exchange) return VC_OK;
     const int Lloc = h->Lloc, P = h->P;
-    const int64_t blk = (int64_t)B * Lloc * (h->cfg.num_heads / P) * 128;      // elements per (peer, q|k|v) block
-    // (q|k|v are already in the exchange layout: written there by the norm + RoPE pass)
+    const int64_t sub = (int64_t)Lloc * (h->cfg.num_heads / P) * 128;          // elements per (tensor, sample, peer) piece
+    // q|k|v are already in the exchange layout send[3][B][P_dst][Lloc][Nl][128], written there by the norm + RoPE pass.  One
+    // all-to-all per (tensor, sample) slab: the pieces of one (tensor, sample) then land next to each other in source-rank =
+    // token order, recv[3][B][P_src][Lloc][Nl][128] = [3][B][L][Nl][128] -- the plain layout of the attention kernel
     { int r = to_comm(h, ln, 0); if (r != VC_OK) return r; }
-    return sp_all_to_all(h, ln, ln.send, ln.recv, 3 * blk * 2, "q/k/v");
+    return sp_all_to_all(h, ln, ln.send, ln.recv, sub * 2, "q/k/v", 3 * B);
 }
 int sa_mid(vc_engine* h, Lane& ln, int B) {
     hipStream_t s = ln.s;
@@ -399,28 +406,27 @@ int sa_mid(vc_engine* h, Lane& ln, int B) {
     // ---- Ulysses: scatter heads / gather sequence, attend over the full sequence with N/P heads, and back ----
     const int Nl = N / P;
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
-    const int64_t blk = (int64_t)B * Lloc * hd;      // elements per (peer, q|k|v) block
+    const int64_t sub = (int64_t)Lloc * hd;          // elements per (tensor, sample, peer) piece
+    const int64_t slab = (int64_t)P * sub;           // one (tensor, sample): the full (padded) sequence, Nl heads
     { int r = from_comm(h, ln, 1); if (r != VC_OK) return r; }
-    // recv: [P_src][3][B][Lloc][Nl][128]; token t of the full sequence = (src = t / Lloc, i = t % Lloc)
+    // recv: [3][B][P_src][Lloc][Nl][128] = [3][B][Lpad][Nl][128]: token t of the full sequence = (src = t / Lloc, i = t % Lloc)
     const char* r = (const char*)ln.recv;
-    a.q = r; a.k = r + blk * 2; a.v = r + 2 * blk * 2;
-    a.q_bs = a.k_bs = a.v_bs = (int64_t)Lloc * hd;
+    a.q = r; a.k = r + (int64_t)B * slab * 2; a.v = r + (int64_t)2 * B * slab * 2;
+    a.q_bs = a.k_bs = a.v_bs = slab;
     a.q_ts = a.k_ts = a.v_ts = hd;
     a.q_hs = a.k_hs = a.v_hs = 128;
-    a.seg_len = Lloc;
-    a.q_ss = a.k_ss = a.v_ss = 3 * blk;
-    // out (send buffer of the return exchange): [P_dst][B][Lloc][Nl][128]
-    a.out = ln.send; a.o_bs = (int64_t)Lloc * hd; a.o_ts = hd; a.o_hs = 128; a.o_ss = blk;
+    // out (send buffer of the return exchange): [B][P_dst = token owner][Lloc][Nl][128] = [B][Lpad][Nl][128]
+    a.out = ln.send; a.o_bs = slab; a.o_ts = hd; a.o_hs = 128;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
     VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
     { int r2 = to_comm(h, ln, 2); if (r2 != VC_OK) return r2; }
-    return sp_all_to_all(h, ln, ln.send, ln.recv, blk * 2, "o");
+    return sp_all_to_all(h, ln, ln.send, ln.recv, sub * 2, "o", B);        // one all-to-all per sample
 }
 int sa_post(vc_engine* h, Lane& ln, int B) {
     if (!h->sp_exchange) return VC_OK;
     { int r = from_comm(h, ln, 3); if (r != VC_OK) return r; }
-    // recv: [P_src = head group][B*Lloc][Nl*128] -> attn[B*Lloc][d]
-    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * h->Lloc, h->cfg.dim, h->P, ln.s));
+    // recv: [B][P_src = head group][Lloc][Nl*128] -> attn[B*Lloc][d]
+    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * h->Lloc, h->Lloc, h->cfg.dim, h->P, ln.s));
     return VC_OK;
 }
 

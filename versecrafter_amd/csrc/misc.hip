@@ -135,13 +135,14 @@ __global__ void pad_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restri
     }
 }
 
-// Ulysses unpack: recv [P][M][hd] -> attn [M, d]
-__global__ void sp_unpack_o_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ attn, int M, int d8, int hd8) {
+// Ulysses unpack: recv [B][P_src = head group][Lloc][hd] -> attn [B * Lloc, d]   (M = B * Lloc rows, rpb = Lloc)
+__global__ void sp_unpack_o_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ attn, int M, int rpb, int d8, int hd8, int P) {
     const int64_t n = (int64_t)M * d8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % d8), row = (int)(i / d8);
         const int src = col / hd8, c = col - src * hd8;
-        ((uint4*)attn)[i] = ((const uint4*)recv)[((int64_t)src * M + row) * hd8 + c];
+        const int b = row / rpb, r = row - b * rpb;
+        ((uint4*)attn)[i] = ((const uint4*)recv)[(((int64_t)b * P + src) * rpb + r) * hd8 + c];
     }
 }
 
@@ -312,10 +313,11 @@ int vc_launch_delay(double usec, hipStream_t st) {
     return ok();
 }
 
-int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st) {
+int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int rows_per_batch, int d, int P, hipStream_t st) {
     if (!recv || !attn || M <= 0 || d <= 0 || P <= 0 || d % (8 * P)) return VC_E_INVALID;
+    if (rows_per_batch <= 0 || M % rows_per_batch) return VC_E_INVALID;
     hipLaunchKernelGGL(sp_unpack_o_kernel, dim3(grid_for((int64_t)M * d / 8, 256)), dim3(256), 0, st,
-                       (const bf16_t*)recv, (bf16_t*)attn, M, d / 8, d / P / 8);
+                       (const bf16_t*)recv, (bf16_t*)attn, M, rows_per_batch, d / 8, d / P / 8, P);
     return ok();
 }
 

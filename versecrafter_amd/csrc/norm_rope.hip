@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
 
 // Self-attention front (WT.py:385-392) in ONE pass over the q|k|v buffer [rows][3 dim]: blockIdx.y = 0 / 1: full-dim RMSNorm + RoPE
 // of q / k (arithmetic of rmsnorm_rope_kernel, bit for bit), blockIdx.y = 2: v.  Written in place (send == nullptr; v is then
-// not launched) or straight into the Ulysses exchange layout send[P_dst][3][rows][dim / P] -- which makes the separate pack pass
+// not launched) or straight into the Ulysses exchange layout send[3][B][P_dst][Lloc][dim / P] -- which makes the separate pack pass
 // (and its second read + write of q|k|v) disappear.
 template <int MAXC, bool PACK>
 __global__ __launch_bounds__(256) void qkv_front_kernel(bf16_t* __restrict__ qkv, int rows, int dim, const bf16_t* __restrict__ wq,
@@ -165,8 +165,11 @@ __global__ __launch_bounds__(256) void qkv_front_kernel(bf16_t* __restrict__ qkv
     bf16_t* xr = qkv + (int64_t)row * 3 * dim + (int64_t)which * dim;
     const int hd = dim / P;
     const float inv_hd = 1.0f / (float)hd;              // idx / hd for idx < 8192, hd >= 128: exact through the reciprocal
-    bf16_t* srow = PACK ? send + ((int64_t)which * rows + row) * hd : nullptr;
-    const int64_t peer_stride = (int64_t)3 * rows * hd;
+    // exchange layout: send[3 (q, k, v)][B][P_dst][Lloc][hd]  (row = b * Lloc + i; Lloc = grid.rows_per_batch)
+    const int rpb = grid.rows_per_batch > 0 ? grid.rows_per_batch : rows;
+    const int sb = row / rpb, si = row - sb * rpb;
+    bf16_t* srow = PACK ? send + ((int64_t)which * P * rows + (int64_t)sb * P * rpb + si) * hd : nullptr;
+    const int64_t peer_stride = (int64_t)rpb * hd;
     auto out_ptr = [&](int idx) -> bf16_t* {
         if (!PACK) return xr + idx;
         const int peer = (int)(((float)idx + 0.5f) * inv_hd);

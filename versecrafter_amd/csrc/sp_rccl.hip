@@ -174,6 +174,32 @@ int vc_comm_all_to_all(VcComm* c, const void* send, void* recv, int64_t bytes_pe
     return VC_OK;
 }
 
+// `n` all-to-alls of equal shape on consecutive slabs (slab j = [P][bytes_per_peer] at offset j * P * bytes_per_peer of send and
+// recv) as ONE RCCL group: one fused launch, every peer still one message per slab.
+int vc_comm_all_to_all_n(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, int n, hipStream_t s) {
+    const Api* a = api();
+    if (!a || !c) return VC_E_STATE;
+    if (n <= 1) return vc_comm_all_to_all(c, send, recv, bytes_per_peer, s);
+    if (bytes_per_peer & 1) { t_err = "all_to_all: odd byte count"; return VC_E_INVALID; }
+    const size_t cnt = (size_t)bytes_per_peer / 2;
+    const int64_t slab = (int64_t)c->world * bytes_per_peer;
+    NCHK(a, a->GroupStart());
+    for (int j = 0; j < n; ++j) {
+        const char* sj = (const char*)send + j * slab;
+        char* rj = (char*)recv + j * slab;
+        if (!c->grouped_p2p) {
+            NCHK(a, a->AllToAll(sj, rj, cnt, ncclBfloat16, c->comm, s));
+        } else {
+            for (int r = 0; r < c->world; ++r) {
+                NCHK(a, a->Send(sj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+                NCHK(a, a->Recv(rj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+            }
+        }
+    }
+    NCHK(a, a->GroupEnd());
+    return VC_OK;
+}
+
 int vc_comm_all_gather(VcComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s) {
     const Api* a = api();
     if (!a || !c) return VC_E_STATE;

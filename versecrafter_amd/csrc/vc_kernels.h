@@ -74,7 +74,7 @@ int vc_launch_rmsnorm_rope(void* x, int64_t ld, int rows, int dim, const void* w
                            hipStream_t stream);
 
 // self-attention front in one pass over qkv [rows][3 dim]: RMSNorm + RoPE of q and k (in place when send == nullptr), or q, k
-// (normed, rotated) and v written straight into the Ulysses exchange layout send[P][3][rows][dim / P]
+// (normed, rotated) and v written straight into the Ulysses exchange layout send[3][B][P][Lloc][dim / P] (rows = B * Lloc, Lloc = grid rows_per_batch)
 int vc_launch_qkv_front(void* qkv, int rows, int dim, const void* wq, const void* wk, float eps, const float2* rope_table,
                         const VcRopeGrid* grid, void* send, int P, hipStream_t stream);
 
@@ -104,10 +104,10 @@ int vc_launch_unipc_update(const void* noise_uncond, const void* noise_cond, con
                            const float* sc, int flags, hipStream_t st);
 int vc_launch_geoada_context(const void* z, const void* mask, int mask_is_f32, void* out, int T, int h, int w, int F,
                              hipStream_t st);
-// Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py).  q|k|v reach the send layout [P_dst][3][M][d/P] through
+// Ulysses exchange buffers (layout contract: versecrafter_amd/dist.py).  q|k|v reach the send layout [3][B][P_dst][Lloc][d/P] through
 // vc_launch_qkv_front; the return path needs:
-//   unpack recv [P_src][M][d/P] -> attn [M, d]
-int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int d, int P, hipStream_t st);
+//   unpack recv [B][P_src][Lloc][d/P] -> attn [M = B * Lloc, d]
+int vc_launch_sp_unpack_o(const void* recv, void* attn, int M, int rows_per_batch, int d, int P, hipStream_t st);
 // one idle wave holds the stream for `usec` microseconds (what-if timing only)
 int vc_launch_delay(double usec, hipStream_t st);
 
@@ -119,5 +119,6 @@ int vc_comm_create(VcComm** out, const void* id128, int world, int rank);   // b
 int vc_comm_ranks(const VcComm* c);
 void vc_comm_destroy(VcComm* c);
 int vc_comm_all_to_all(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t s);
+int vc_comm_all_to_all_n(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, int n, hipStream_t s);   // n slabs, one group
 int vc_comm_all_gather(VcComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s);
 const char* vc_comm_error();    // message of the calling thread's last failed vc_comm_* call

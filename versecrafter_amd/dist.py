@@ -7,10 +7,12 @@ all-to-all around self-attention and the final all-gather.  The HIP engine packs
 buffers itself and runs the collectives on its own RCCL communicators (include/vcengine.h: vc_sp_init_rccl); the callback
 transport (vc_sp_init) stays for the gloo tests.
 
-Layout contract of one exchange (P ranks, B samples, Lloc = L/P local tokens, Nl = N/P local heads):
-    send  [P_dst][3 (q,k,v)][B][Lloc][Nl][128]  --all_to_all-->  recv [P_src][3][B][Lloc][Nl][128]
-    attention over the full sequence (token t = src * Lloc + i) with Nl heads writes
-    send  [P_dst (token owner)][B][Lloc][Nl][128] --all_to_all--> recv [P_src (head group)][B][Lloc][Nl][128]
+Layout contract of one exchange (P ranks, B samples, Lloc = L/P local tokens, Nl = N/P local heads): one all-to-all per
+(tensor, sample) slab, so that what arrives is already the plain [B][L][Nl][128] layout of the attention kernel --
+    send  [3 (q,k,v)][B][P_dst][Lloc][Nl][128]  --3 B all_to_alls-->  recv [3][B][P_src][Lloc][Nl][128] = [3][B][L][Nl][128]
+    attention over the full sequence (token t = src * Lloc + i) with Nl heads writes [B][L][Nl][128] =
+    send  [B][P_dst (token owner)][Lloc][Nl][128] --B all_to_alls--> recv [B][P_src (head group)][Lloc][Nl][128]
+(on RCCL the slabs of one exchange are one group = one fused launch; a rank still sends one message per peer and slab)
 `pack_qkv` / `unpack_tokens` / `pack_out` / `unpack_heads` below restate that contract on torch tensors; the
 multi-process CPU tests (gloo) drive them together with the byte-level collectives the engine uses.
 """
@@ -166,28 +168,36 @@ def all_gather_bytes(send: torch.Tensor, recv: torch.Tensor, group=None):
 
 # ---- the exchange-buffer layout contract, on tensors ----------------------------------------------
 def pack_qkv(qkv: torch.Tensor, P: int) -> torch.Tensor:
-    """qkv [B, Lloc, 3, N, D] -> send [P, 3, B, Lloc, N/P, D]."""
+    """qkv [B, Lloc, 3, N, D] (local tokens, all heads) -> send [3, B, P_dst, Lloc, N/P, D]."""
     B, Lloc, three, N, D = qkv.shape
-    return qkv.view(B, Lloc, 3, P, N // P, D).permute(3, 2, 0, 1, 4, 5).contiguous()
+    return qkv.view(B, Lloc, 3, P, N // P, D).permute(2, 0, 3, 1, 4, 5).contiguous()
 
 
 def unpack_tokens(recv: torch.Tensor):
-    """recv [P_src, 3, B, Lloc, Nl, D] -> q, k, v each [B, P*Lloc, Nl, D] (token t = src*Lloc + i)."""
-    P, three, B, Lloc, Nl, D = recv.shape
-    full = recv.permute(1, 2, 0, 3, 4, 5).reshape(3, B, P * Lloc, Nl, D)
+    """recv [3, B, P_src, Lloc, Nl, D] -> q, k, v each [B, P*Lloc, Nl, D] (token t = src*Lloc + i): a view, no data movement."""
+    three, B, P, Lloc, Nl, D = recv.shape
+    full = recv.reshape(3, B, P * Lloc, Nl, D)
     return full[0], full[1], full[2]
 
 
 def pack_out(o: torch.Tensor, P: int) -> torch.Tensor:
-    """o [B, P*Lloc, Nl, D] -> send [P_dst, B, Lloc, Nl, D]."""
+    """o [B, P*Lloc, Nl, D] -> send [B, P_dst, Lloc, Nl, D]: a view."""
     B, L, Nl, D = o.shape
-    return o.view(B, P, L // P, Nl, D).permute(1, 0, 2, 3, 4).contiguous()
+    return o.contiguous().view(B, P, L // P, Nl, D)
 
 
 def unpack_heads(recv: torch.Tensor) -> torch.Tensor:
-    """recv [P_src, B, Lloc, Nl, D] -> [B, Lloc, P*Nl, D] (head = src*Nl + hl)."""
-    P, B, Lloc, Nl, D = recv.shape
-    return recv.permute(1, 2, 0, 3, 4).reshape(B, Lloc, P * Nl, D)
+    """recv [B, P_src, Lloc, Nl, D] -> [B, Lloc, P*Nl, D] (head = src*Nl + hl)."""
+    B, P, Lloc, Nl, D = recv.shape
+    return recv.permute(0, 2, 1, 3, 4).reshape(B, Lloc, P * Nl, D)
+
+
+def all_to_all_slabs(send: torch.Tensor, recv: torch.Tensor, nslab: int, group=None):
+    """`nslab` all-to-alls on the leading slabs of send / recv (each slab = P equal pieces)."""
+    s8, r8 = send.view(torch.uint8).flatten(), recv.view(torch.uint8).flatten()
+    n = s8.numel() // nslab
+    for j in range(nslab):
+        all_to_all_bytes(s8[j * n:(j + 1) * n], r8[j * n:(j + 1) * n], group)
 
 
 def ulysses_attention(q, k, v, attn_fn, group=None):
@@ -197,12 +207,12 @@ def ulysses_attention(q, k, v, attn_fn, group=None):
     B, Lloc, N, D = q.shape
     send = pack_qkv(torch.stack([q, k, v], dim=2), P)
     recv = torch.empty_like(send)
-    all_to_all_bytes(send.view(torch.uint8).flatten(), recv.view(torch.uint8).flatten(), group)
+    all_to_all_slabs(send, recv, 3 * B, group)
     qf, kf, vf = unpack_tokens(recv)
     o = attn_fn(qf, kf, vf)
     send2 = pack_out(o.contiguous(), P)
     recv2 = torch.empty_like(send2)
-    all_to_all_bytes(send2.view(torch.uint8).flatten(), recv2.view(torch.uint8).flatten(), group)
+    all_to_all_slabs(send2, recv2, B, group)
     return unpack_heads(recv2)
 
 

@@ -149,14 +149,16 @@ def rmsnorm_rope_(x, weight, eps=1e-6, table=None, grid=None, token_offset=0, ro
 
 def qkv_front(qkv, wq, wk, table, grid, token_offset=0, rows_per_batch=0, eps=1e-6, P=1, pack=False):
     """Self-attention front on qkv [rows, 3*dim] (contiguous): WanRMSNorm + rope_apply of the q and k thirds in ONE pass.
-    pack=False: in place, returns qkv.  pack=True: returns send [P, 3, rows, dim/P] -- q, k (normed, rotated) and v in the
-    Ulysses exchange layout; qkv is left untouched."""
+    pack=False: in place, returns qkv.  pack=True: returns send [3, B, P, Lloc, dim/P] (B * Lloc = rows, Lloc = rows_per_batch or
+    rows) -- q, k (normed, rotated) and v in the Ulysses exchange layout (dist.pack_qkv); qkv is left untouched."""
     lib = _lib.load()
     _chk(qkv, "qkv"); _chk(wq, "wq"); _chk(wk, "wk"); _chk(table, "table", torch.float32)
     assert qkv.is_contiguous() and qkv.shape[1] % 3 == 0
     rows, dim = qkv.shape[0], qkv.shape[1] // 3
     g = (C.c_int32 * 5)(int(grid[0]), int(grid[1]), int(grid[2]), int(token_offset), int(rows_per_batch))
-    send = torch.empty(P, 3, rows, dim // P, dtype=torch.bfloat16, device=qkv.device) if pack else None
+    rpb = int(rows_per_batch) if rows_per_batch else rows
+    assert rows % rpb == 0
+    send = torch.empty(3, rows // rpb, P, rpb, dim // P, dtype=torch.bfloat16, device=qkv.device) if pack else None
     rc = lib.vc_op_qkv_front(_ptr(qkv), rows, dim, _ptr(wq), _ptr(wk), eps, _ptr(table), g, _ptr(send), P, _stream())
     _lib.check(rc)
     return send if pack else qkv
