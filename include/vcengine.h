@@ -80,7 +80,10 @@ int vc_set_rope_table(vc_engine* h, const double* cis, int rows, int cols);
  * The self-attention exchange (third-party usp_attn_forward, bound at WT.py:907-921) is delegated to the host
  * through two callbacks so that the collective itself stays in torch.distributed / RCCL:
  *   all_to_all(ctx, send, recv, bytes_per_peer, stream): peer r's slice is send[r*bytes_per_peer ...]
- *   all_gather(ctx, send, recv, bytes, stream)                                                          */
+ *   all_gather(ctx, send, recv, bytes, stream)
+ * One exchange of a block is several such all-to-alls on consecutive slabs of the engine's buffers -- one per (q|k|v tensor,
+ * sample) before the attention, one per sample after it (layout: versecrafter_amd/dist.py) -- so that what arrives is the
+ * attention kernel's plain [B][L][heads / world][128] layout; the callback is invoked once per slab.                       */
 typedef int (*vc_all_to_all_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
 typedef int (*vc_all_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes, void* stream);
 int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_gather_fn ag, void* ctx);
@@ -94,7 +97,8 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
  *   vc_rccl_unique_id : rank 0 fills out[128] (ncclGetUniqueId); the host ships the bytes to every rank (any side channel).
  *   vc_sp_init_rccl   : unique_ids = n_ids x 128 bytes, n_ids must be 2 (chain 0, chain 1); every rank of the world must
  *                       call it (ncclCommInitRank is a rendezvous).  flags: VC_SP_FORCE_EXCHANGE runs the exchange path
- *                       (pack, all-to-all, segmented attention, all-to-all, unpack, all-gather) even at world == 1.
+ *                       (pack, all-to-alls, attention, all-to-alls, unpack, all-gather) even at world == 1.  The slabs of one
+ *                       exchange are enqueued as ONE RCCL group (one fused launch).
  *   vc_sp_comm_ranks  : ncclCommCount of chain 0's communicator (0: the RCCL transport is not active).
  *   vc_sp_all_to_all / vc_sp_all_gather : the engine's collectives in isolation (tests): byte buffers, chain 0 or 1. */
 #define VC_RCCL_UNIQUE_ID_BYTES 128
