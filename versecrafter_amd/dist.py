@@ -26,7 +26,6 @@ from . import _lib
 
 _SP_GROUP = None
 _BP_GROUP = None       # batch-parallel group (the samples of a CFG pair on different ranks); None = off
-_SP_DEGREE = 1
 
 
 def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1):
@@ -38,11 +37,9 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
     data-path collective at all; only the noise prediction (4 MB at cfg-3) is all-gathered after the forward.  World size =
     cfg_degree * ulysses_degree * ring_degree; rank r works on sample r // S inside the Ulysses group of its S = ulysses * ring
     neighbours [r - r % S, r - r % S + S)."""
-    global _SP_GROUP, _BP_GROUP, _SP_DEGREE
     degree = int(ulysses_degree) * int(ring_degree)
     cfg_degree = int(cfg_degree)
     world = degree * cfg_degree
-    _SP_DEGREE = degree
     if world > 1:
         if not dist.is_initialized():
             # host-side gloo for rendezvous / object broadcast (the ncclUniqueIds of the engine's communicators), torch's
@@ -63,11 +60,10 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
 def make_groups(sp_degree: int, cfg_degree: int = 1):
     """The process groups of set_multi_gpus_devices on an initialised world of cfg_degree * sp_degree ranks (callers that pick
     their own devices: bench.py's one-GPU rehearsal).  Returns (sp_group or None, bp_group or None)."""
-    global _SP_GROUP, _BP_GROUP, _SP_DEGREE
+    global _SP_GROUP, _BP_GROUP
     world = dist.get_world_size()
     if world != sp_degree * cfg_degree:
         raise ValueError(f"cfg_degree*sp_degree = {sp_degree * cfg_degree} but world size is {world}")
-    _SP_DEGREE = sp_degree
     _SP_GROUP = _BP_GROUP = None
     if cfg_degree == 1:
         _SP_GROUP = dist.group.WORLD
