@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bitwise pre-flight of a GEMM kernel variant against tile 2 at awkward shapes (GPU box only) before a timing A/B:
+"""Bitwise pre-flight of a GEMM kernel variant against tile 2 at awkward shapes (GPU box only, 3 repeats) before a timing A/B:
    python tools/ab_gemm_small.py 5"""
 import os
 import sys
@@ -23,7 +23,7 @@ for (M, N, K, epi) in ((1024, 256, 128, 0), (1024, 256, 256, 0), (1500, 512, 384
     resid = torch.randn(M, N, device="cuda", generator=g).bfloat16() if epi == 3 else None
     gate = torch.randn(2, N, device="cuda", generator=g).bfloat16() if epi == 3 else None
     ref = ops.gemm(a, w, bias, epilogue=epi, resid=resid, gate=gate, rows_per_batch=M // 2, tile=2)
-    for rep in range(2):
+    for rep in range(3):
         out = ops.gemm(a, w, bias, epilogue=epi, resid=resid, gate=gate, rows_per_batch=M // 2, tile=t)
         torch.cuda.synchronize()
         same = torch.equal(out, ref)
