@@ -485,11 +485,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
     const bool wide = (p.ldc & 7) == 0 && ((uintptr_t)C & 15) == 0;      // rows of C 16-byte aligned
+    // sample index of a row without a vector division: a tile of 256 rows crosses at most one sample boundary when rpb >= 256
+    const int b_first = m0 / rpb;                                         // wave-uniform (scalar) division, once per tile
+    const int m_next = (b_first + 1) * rpb;                               // first row of the next sample
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= p.M) continue;
-        const int b = m / rpb;
+        const int b = rpb >= 256 ? b_first + (m >= m_next ? 1 : 0) : m / rpb;
         const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
