@@ -18,19 +18,31 @@ from versecrafter_amd import _lib, ops
 lib = _lib.load()
 lib.vc_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
 M, N = 65536, 5120
+EPI = int(os.environ.get("EPI", "-1"))        # -1: no bias, plain store; 0 / 1 / 3: the engine's epilogues with bias (3: + gate, residual in place)
 for K in (int(k) for k in (sys.argv[1:] or ["5120"])):
     g = torch.Generator(device="cuda").manual_seed(0)
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    kw = {}
+    if EPI >= 0:
+        kw = dict(bias=torch.randn(N, device="cuda", generator=g).bfloat16(), epilogue=EPI)
+        if EPI == 3:
+            kw.update(resid=out, gate=torch.randn(2, N, device="cuda", generator=g).bfloat16(), rows_per_batch=M // 2)
     ntiles = (M // 256) * (N // 256)
     grid = (ntiles + 7) // 8 * 8
     buf = torch.zeros(grid, 8, dtype=torch.int64, device="cuda")
+    def run():
+        if EPI >= 0:
+            b_ = kw["bias"]
+            ops.gemm(a, w, b_, out=out, tile=4, **{k: v for k, v in kw.items() if k != "bias"})
+        else:
+            ops.gemm(a, w, None, out=out, tile=4)
     for _ in range(3):
-        ops.gemm(a, w, None, out=out, tile=4)
+        run()
     torch.cuda.synchronize()
     assert lib.vc_debug_set_gemm_trace(buf.data_ptr()) == 0
-    ops.gemm(a, w, None, out=out, tile=4)
+    run()
     torch.cuda.synchronize()
     lib.vc_debug_set_gemm_trace(None)
     t = buf.cpu().numpy()
@@ -48,7 +60,7 @@ for K in (int(k) for k in (sys.argv[1:] or ["5120"])):
             gaps.append(us(s1 - e0))
     span = us(t[:, 7].max() - t[:, 0].min())
     med = statistics.median
-    print(f"K={K}: {len(t)} workgroups on {len(per_cu)} CUs, kernel span {span:.1f} us")
+    print(f"K={K} EPI={EPI}: {len(t)} workgroups on {len(per_cu)} CUs, kernel span {span:.1f} us")
     print(f"  prologue (entry -> first K pair)      median {med(pro):6.2f} us   p90 {sorted(pro)[int(.9 * len(pro))]:6.2f}")
     print(f"  main loop                             median {med(loop):6.2f} us   p90 {sorted(loop)[int(.9 * len(loop))]:6.2f}"
           f"   ({med(loop) / (K // 64):.3f} us per K-tile)")

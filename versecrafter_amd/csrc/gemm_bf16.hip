@@ -477,7 +477,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #endif
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    // (kept inline in both kernels on purpose: factored into one shared device function it compiled 1-2 % slower)
+    // Everything the epilogue READS is fetched before its first store: the bias and the gate of the tile's sample once per wave
+    // (they do not depend on the row), the residual (and hint) rows of a whole pass as one batch of loads.  C may alias the
+    // residual (the engine adds in place), so with loads and stores interleaved fragment by fragment every load had to wait for
+    // the store before it: 32 memory round trips in a row, 27.6 us per tile for the gated-residual epilogue against 4.2 us for a
+    // plain store (tools/trace_gemm.py, round 2).  Same arithmetic per element, same results.
     const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
     const bf16_t* resid = (const bf16_t*)p.resid;
     const bf16_t* gate = (const bf16_t*)p.gate;
@@ -488,70 +492,112 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     // sample index of a row without a vector division: a tile of 256 rows crosses at most one sample boundary when rpb >= 256
     const int b_first = m0 / rpb;                                         // wave-uniform (scalar) division, once per tile
     const int m_next = (b_first + 1) * rpb;                               // first row of the next sample
+    const bool one_sample = rpb >= 256 && m0 + 256 <= m_next;             // all rows of the tile belong to sample b_first
+    constexpr bool NEED_R = EPI == VC_EPI_BIAS_RESID || EPI == VC_EPI_GELU_MUL || EPI == VC_EPI_BIAS_GATE_RESID;
+    const int nb = n0 + wc * 64 + (lane >> 4) * 4;                        // this lane's first column in block j = 0
+    uint2 bbp[4], ggp[4];      // kept packed (bf16 x 4): the gated-residual form needs every register for its batch of loads
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int b = rpb >= 256 ? b_first + (m >= m_next ? 1 : 0) : m / rpb;
-        const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+    for (int j = 0; j < 4; ++j) {
+        bbp[j] = bias ? *(const uint2*)(bias + nb + j * 16) : uint2{0u, 0u};
+        if (EPI == VC_EPI_BIAS_GATE_RESID) ggp[j] = *(const uint2*)(gate + (int64_t)b_first * p.gate_bstride + nb + j * 16);
+    }
+    uint2 rr[32], hh[16];      // residual fragments of a pass (32 without a hint, 16 + 16 hint fragments with one)
+    auto pass = [&](auto i0_c, auto i1_c, auto hint_c) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
+        constexpr bool HINT = decltype(hint_c)::value;
+        if (NEED_R) {
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-        uint2 pk[2];
+            for (int i = I0; i < I1; ++i) {
+                const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+                if (m < p.M) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = jp * 2 + jj;
-            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (bias) {
-                float bb[4];
-                unpack4(*(const uint2*)(bias + n), bb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bb[e];
-            }
-            if (EPI == VC_EPI_BIAS_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
-            } else if (EPI == VC_EPI_BIAS_RESID) {
-                float r[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
-            } else if (EPI == VC_EPI_GELU_MUL) {
-                float r[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
-            } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
-                float r[4], gg[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-                unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), gg);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * gg[e]);
-                if (hint) {
-                    float hv[4];
-                    unpack4(*(const uint2*)(hint + (int64_t)m * p.ldh + n), hv);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(hv[e] * p.hint_scale);
+                    for (int j = 0; j < 4; ++j) {
+                        rr[(i - I0) * 4 + j] = *(const uint2*)(resid + (int64_t)m * p.ldr + nb + j * 16);
+                        if (HINT) hh[(i - I0) * 4 + j] = *(const uint2*)(hint + (int64_t)m * p.ldh + nb + j * 16);
+                    }
                 }
             }
-            if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
-            pk[jj] = pack4(v);
+            __builtin_amdgcn_sched_barrier(0);         // no store of this pass before its last load has been issued
         }
-        // two neighbouring 16-column blocks -> 16-byte stores: the lane groups (rows of 16 lanes) g and g^1 trade halves so that
-        // even groups hold 8 consecutive columns of block 2jp, odd groups of block 2jp+1 (v_permlane16_swap: odd rows of the
-        // first operand <-> even rows of the second); a store then covers 64 contiguous bytes per row instead of 32
-        if (wide) {
-            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-            const int g = lane >> 4;
-            const int n = n0 + wc * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
-            *(uint4*)(C + (int64_t)m * p.ldc + n) = uint4{s0[0], s1[0], s0[1], s1[1]};
-        } else {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                *(uint2*)(C + (int64_t)m * p.ldc + n0 + wc * 64 + (jp * 2 + jj) * 16 + (lane >> 4) * 4) = pk[jj];
+        for (int i = I0; i < I1; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const int b = rpb >= 256 ? b_first + (m >= m_next ? 1 : 0) : m / rpb;
+            const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+            const unsigned keep = dead ? 0u : 0xFFFFFFFFu;            // rows past valid_rows are written as +0.0
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                uint2 pk[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp * 2 + jj;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (bias) {
+                        float bb[4];
+                        unpack4(bbp[j], bb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bb[e];
+                    }
+                    if (EPI == VC_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
+                    } else if (EPI == VC_EPI_BIAS_RESID) {
+                        float r[4];
+                        unpack4(rr[(i - I0) * 4 + j], r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+                    } else if (EPI == VC_EPI_GELU_MUL) {
+                        float r[4];
+                        unpack4(rr[(i - I0) * 4 + j], r);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
+                    } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
+                        float r[4], g4[4];
+                        unpack4(rr[(i - I0) * 4 + j], r);
+                        if (one_sample) {
+                            unpack4(ggp[j], g4);
+                        } else {                                     // the tile straddles two samples (or rpb < 256): gate per row
+                            unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + nb + j * 16), g4);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * g4[e]);
+                        if (HINT) {
+                            float hv[4];
+                            unpack4(hh[(i - I0) * 4 + j], hv);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(hv[e] * p.hint_scale);
+                        }
+                    }
+                    pk[jj] = pack4(v);
+                    pk[jj].x &= keep;
+                    pk[jj].y &= keep;
+                }
+                // two neighbouring 16-column blocks -> 16-byte stores: the lane groups (rows of 16 lanes) g and g^1 trade halves so
+                // that even groups hold 8 consecutive columns of block 2jp, odd groups of block 2jp+1 (v_permlane16_swap: odd rows
+                // of the first operand <-> even rows of the second); a store then covers 64 contiguous bytes per row instead of 32
+                if (wide) {
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                    const int g = lane >> 4;
+                    const int n = n0 + wc * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
+                    *(uint4*)(C + (int64_t)m * p.ldc + n) = uint4{s0[0], s1[0], s0[1], s1[1]};
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        *(uint2*)(C + (int64_t)m * p.ldc + nb + (jp * 2 + jj) * 16) = pk[jj];
+                }
+            }
         }
-        }
+    };
+    using I0_ = std::integral_constant<int, 0>;
+    using I4_ = std::integral_constant<int, 4>;
+    using I8_ = std::integral_constant<int, 8>;
+    if (EPI == VC_EPI_BIAS_GATE_RESID && hint) {
+        pass(I0_{}, I4_{}, std::true_type{});
+        pass(I4_{}, I8_{}, std::true_type{});
+    } else {
+        pass(I0_{}, I8_{}, std::false_type{});
     }
 #ifdef VC_PP_TRACE
     if (trc && tid == 0) {
