@@ -296,7 +296,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 // branches this kernel was 52 KB of code, most of it unrolled epilogue, against a 64 KB instruction cache shared by two
 // CUs; per kind it is 11-24 KB (round 2: 0-2 % at the cfg-3 shapes, same-box A/B).
 // =====================================================================================================
-template <int EPI>
+template <int EPI, bool HINT = false>      // HINT: the gated-residual epilogue also adds a hint (VC.py:146-147)
 __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int per_xcd = gridDim.x >> 3;
@@ -477,43 +477,48 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #endif
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    // Everything the epilogue READS is fetched before its first store: the bias and the gate of the tile's sample once per wave
-    // (they do not depend on the row), the residual (and hint) rows of a whole pass as one batch of loads.  C may alias the
-    // residual (the engine adds in place), so with loads and stores interleaved fragment by fragment every load had to wait for
-    // the store before it: 32 memory round trips in a row, 27.6 us per tile for the gated-residual epilogue against 4.2 us for a
-    // plain store (tools/trace_gemm.py, round 2).  Same arithmetic per element, same results.
+    // Everything the epilogue READS is fetched before its first store: the bias and the gate of the tile's (at most two) samples
+    // once per wave (they do not depend on the row), the residual (and hint) rows of a whole pass as one batch of loads.  C may
+    // alias the residual (the engine adds in place), so with loads and stores interleaved fragment by fragment every load had
+    // to wait for the store before it: 32 memory round trips in a row, 27.6 us per tile for the gated-residual epilogue against
+    // 4.2 us for a plain store (tools/trace_gemm.py, round 2).  Same arithmetic per element, same results.  The launcher
+    // guarantees 16-byte aligned rows of C and rows_per_batch >= 256 (a tile of 256 rows then touches at most two samples).
     const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
     const bf16_t* resid = (const bf16_t*)p.resid;
     const bf16_t* gate = (const bf16_t*)p.gate;
     const bf16_t* hint = (const bf16_t*)p.hint;
     bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
-    const bool wide = (p.ldc & 7) == 0 && ((uintptr_t)C & 15) == 0;      // rows of C 16-byte aligned
-    // sample index of a row without a vector division: a tile of 256 rows crosses at most one sample boundary when rpb >= 256
     const int b_first = m0 / rpb;                                         // wave-uniform (scalar) division, once per tile
     const int m_next = (b_first + 1) * rpb;                               // first row of the next sample
-    const bool one_sample = rpb >= 256 && m0 + 256 <= m_next;             // all rows of the tile belong to sample b_first
+    const int b_last = (p.M - 1) / rpb;
     constexpr bool NEED_R = EPI == VC_EPI_BIAS_RESID || EPI == VC_EPI_GELU_MUL || EPI == VC_EPI_BIAS_GATE_RESID;
     const int nb = n0 + wc * 64 + (lane >> 4) * 4;                        // this lane's first column in block j = 0
-    uint2 bbp[4], ggp[4];      // kept packed (bf16 x 4): the gated-residual form needs every register for its batch of loads
+    const int g16 = lane >> 4;
+    const int nst = n0 + wc * 64 + (g16 & 1) * 16 + (g16 >> 1) * 8;       // first column of this lane's 16-byte store in pair jp = 0
+    uint2 bbp[4], ggp[2][4];   // kept packed (bf16 x 4): the gated-residual form needs every register for its batch of loads
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         bbp[j] = bias ? *(const uint2*)(bias + nb + j * 16) : uint2{0u, 0u};
-        if (EPI == VC_EPI_BIAS_GATE_RESID) ggp[j] = *(const uint2*)(gate + (int64_t)b_first * p.gate_bstride + nb + j * 16);
+        if (EPI == VC_EPI_BIAS_GATE_RESID) {
+            ggp[0][j] = *(const uint2*)(gate + (int64_t)b_first * p.gate_bstride + nb + j * 16);
+            ggp[1][j] = *(const uint2*)(gate + (int64_t)(b_first < b_last ? b_first + 1 : b_last) * p.gate_bstride + nb + j * 16);
+        }
     }
-    uint2 rr[32], hh[16];      // residual fragments of a pass (32 without a hint, 16 + 16 hint fragments with one)
-    auto pass = [&](auto i0_c, auto i1_c, auto hint_c) __attribute__((always_inline)) {
+    uint2 rr[HINT ? 16 : 32], hh[16];      // residual fragments of a pass (32 without a hint, 16 + 16 hint fragments with one)
+    auto pass = [&](auto i0_c, auto i1_c) __attribute__((always_inline)) {
         constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
-        constexpr bool HINT = decltype(hint_c)::value;
         if (NEED_R) {
 #pragma unroll
             for (int i = I0; i < I1; ++i) {
                 const int m = m0 + wr * 128 + i * 16 + (lane & 15);
                 if (m < p.M) {
+                    const bf16_t* rrow = resid + (int64_t)m * p.ldr + nb;
+                    const bf16_t* hrow = HINT ? hint + (int64_t)m * p.ldh + nb : nullptr;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        rr[(i - I0) * 4 + j] = *(const uint2*)(resid + (int64_t)m * p.ldr + nb + j * 16);
-                        if (HINT) hh[(i - I0) * 4 + j] = *(const uint2*)(hint + (int64_t)m * p.ldh + nb + j * 16);
+                        rr[(i - I0) * 4 + j] = *(const uint2*)(rrow + j * 16);
+                        if (HINT) hh[(i - I0) * 4 + j] = *(const uint2*)(hrow + j * 16);
                     }
                 }
             }
@@ -523,9 +528,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
         for (int i = I0; i < I1; ++i) {
             const int m = m0 + wr * 128 + i * 16 + (lane & 15);
             if (m >= p.M) continue;
-            const int b = rpb >= 256 ? b_first + (m >= m_next ? 1 : 0) : m / rpb;
-            const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+            const bool second = m >= m_next;                          // row of the tile's second sample
+            const bool dead = p.valid_rows >= 0 && (m - (second ? m_next : b_first * rpb)) >= p.valid_rows;
             const unsigned keep = dead ? 0u : 0xFFFFFFFFu;            // rows past valid_rows are written as +0.0
+            bf16_t* crow = C + (int64_t)m * p.ldc + nst;
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 uint2 pk[2];
@@ -555,11 +561,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                     } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
                         float r[4], g4[4];
                         unpack4(rr[(i - I0) * 4 + j], r);
-                        if (one_sample) {
-                            unpack4(ggp[j], g4);
-                        } else {                                     // the tile straddles two samples (or rpb < 256): gate per row
-                            unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + nb + j * 16), g4);
-                        }
+                        const uint2 gsel = uint2{second ? ggp[1][j].x : ggp[0][j].x, second ? ggp[1][j].y : ggp[0][j].y};
+                        unpack4(gsel, g4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * g4[e]);
                         if (HINT) {
@@ -573,31 +576,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                     pk[jj].x &= keep;
                     pk[jj].y &= keep;
                 }
-                // two neighbouring 16-column blocks -> 16-byte stores: the lane groups (rows of 16 lanes) g and g^1 trade halves so
-                // that even groups hold 8 consecutive columns of block 2jp, odd groups of block 2jp+1 (v_permlane16_swap: odd rows
-                // of the first operand <-> even rows of the second); a store then covers 64 contiguous bytes per row instead of 32
-                if (wide) {
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-                    const int g = lane >> 4;
-                    const int n = n0 + wc * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
-                    *(uint4*)(C + (int64_t)m * p.ldc + n) = uint4{s0[0], s1[0], s0[1], s1[1]};
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        *(uint2*)(C + (int64_t)m * p.ldc + nb + (jp * 2 + jj) * 16) = pk[jj];
-                }
+                // two neighbouring 16-column blocks -> one 16-byte store: the lane groups (rows of 16 lanes) g and g^1 trade halves
+                // so that even groups hold 8 consecutive columns of block 2jp, odd groups of block 2jp+1 (v_permlane16_swap: odd
+                // rows of the first operand <-> even rows of the second); a store covers 64 contiguous bytes per row instead of 32
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                *(uint4*)(crow + jp * 32) = uint4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
     };
     using I0_ = std::integral_constant<int, 0>;
     using I4_ = std::integral_constant<int, 4>;
     using I8_ = std::integral_constant<int, 8>;
-    if (EPI == VC_EPI_BIAS_GATE_RESID && hint) {
-        pass(I0_{}, I4_{}, std::true_type{});
-        pass(I4_{}, I8_{}, std::true_type{});
+    if (HINT) {
+        pass(I0_{}, I4_{});
+        pass(I4_{}, I8_{});
     } else {
-        pass(I0_{}, I8_{}, std::false_type{});
+        pass(I0_{}, I8_{});
     }
 #ifdef VC_PP_TRACE
     if (trc && tid == 0) {
@@ -608,16 +603,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool HINT = false>
 int launch_pp_e(const VcGemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 65536;
     static std::atomic<uint64_t> attr_done{0};
-    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel<EPI>, LDS)) return VC_E_HIP;
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel<EPI, HINT>, LDS)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, HINT>), dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 int launch_pp(const VcGemmParams& p, hipStream_t stream) {
@@ -625,7 +620,8 @@ int launch_pp(const VcGemmParams& p, hipStream_t stream) {
         case VC_EPI_BIAS: return launch_pp_e<VC_EPI_BIAS>(p, stream);
         case VC_EPI_BIAS_GELU: return launch_pp_e<VC_EPI_BIAS_GELU>(p, stream);
         case VC_EPI_BIAS_RESID: return launch_pp_e<VC_EPI_BIAS_RESID>(p, stream);
-        case VC_EPI_BIAS_GATE_RESID: return launch_pp_e<VC_EPI_BIAS_GATE_RESID>(p, stream);
+        case VC_EPI_BIAS_GATE_RESID:
+            return p.hint ? launch_pp_e<VC_EPI_BIAS_GATE_RESID, true>(p, stream) : launch_pp_e<VC_EPI_BIAS_GATE_RESID>(p, stream);
         case VC_EPI_GELU_MUL: return launch_pp_e<VC_EPI_GELU_MUL>(p, stream);
     }
     return VC_E_INVALID;
@@ -925,7 +921,10 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (p.tile == 2 || p.tile == 5) big = true;
     // every tile row readable (M a multiple of 256 or padded buffers), N % 256 == 0, K % 128 == 0: ping-pong kernel
     const bool rows_ok = (p.M % 256 == 0) || p.a_rows_padded;
-    if (big && rows_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
+    // its epilogue stores 16 bytes per lane and holds the gate of at most two samples per tile
+    bool epi_ok = p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (p.rows_per_batch == 0 || p.rows_per_batch >= 256);
+    for (int g = 1; g < p.ngroups; ++g) epi_ok = epi_ok && ((uintptr_t)p.Cg[g - 1] & 15) == 0;
+    if (big && rows_ok && epi_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
         (p.tile == 0 || p.tile == 4 || p.tile == 5))
         return p.tile == 5 ? launch_sw(p, stream) : launch_pp(p, stream);
     // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
