@@ -215,58 +215,92 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----
-    // (kept inline in both kernels on purpose: factored into one shared device function it compiled 1-2 % slower)
+    // As in the ping-pong kernel below: what a chunk of (at most 4) row blocks READS -- residual, hint, gate -- is loaded as one
+    // batch before the chunk's first store (C may alias the residual, so interleaved loads would each wait for the store in front
+    // of them); the bias depends on the column only and is loaded once.  Same arithmetic per element.
     const bf16_t* bias = (const bf16_t*)(grp == 0 ? p.bias : p.biasg[grp - 1]);
     const bf16_t* resid = (const bf16_t*)p.resid;
     const bf16_t* gate = (const bf16_t*)p.gate;
     const bf16_t* hint = (const bf16_t*)p.hint;
     bf16_t* C = (bf16_t*)(grp == 0 ? p.C : p.Cg[grp - 1]);
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+    constexpr bool NEED_R = EPI == VC_EPI_BIAS_RESID || EPI == VC_EPI_GELU_MUL || EPI == VC_EPI_BIAS_GATE_RESID;
+    constexpr int CH = MI < 4 ? MI : 4;                      // row blocks per chunk
+    const int nb = n0 + wn * Cfg::WTN + (lane >> 4) * 4;
+    uint2 bbp[NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * Cfg::WTM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int b = m / rpb;
-        const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+    for (int j = 0; j < NI; ++j) bbp[j] = (bias && nb + j * 16 < p.N) ? *(const uint2*)(bias + nb + j * 16) : uint2{0u, 0u};
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * Cfg::WTN + j * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (bias) {
-                float bb[4];
-                unpack4(*(const uint2*)(bias + n), bb);
+    for (int i0 = 0; i0 < MI; i0 += CH) {
+        uint2 rr[CH * NI], hh[CH * NI], gq[CH * NI];
+        if (NEED_R) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bb[e];
-            }
-            if (EPI == VC_EPI_BIAS_GELU) {
+            for (int ii = 0; ii < CH; ++ii) {
+                const int m = m0 + wm * Cfg::WTM + (i0 + ii) * 16 + (lane & 15);
+                if (m < p.M) {
+                    const int b = m / rpb;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
-            } else if (EPI == VC_EPI_BIAS_RESID) {
-                float r[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
-            } else if (EPI == VC_EPI_GELU_MUL) {
-                float r[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
-            } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
-                float r[4], g[4];
-                unpack4(*(const uint2*)(resid + (int64_t)m * p.ldr + n), r);
-                unpack4(*(const uint2*)(gate + (int64_t)b * p.gate_bstride + n), g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * g[e]);
-                if (hint) {
-                    float h[4];
-                    unpack4(*(const uint2*)(hint + (int64_t)m * p.ldh + n), h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(h[e] * p.hint_scale);
+                    for (int j = 0; j < NI; ++j) {
+                        const int n = nb + j * 16;
+                        if (n < p.N) {
+                            rr[ii * NI + j] = *(const uint2*)(resid + (int64_t)m * p.ldr + n);
+                            if (EPI == VC_EPI_BIAS_GATE_RESID) {
+                                gq[ii * NI + j] = *(const uint2*)(gate + (int64_t)b * p.gate_bstride + n);
+                                if (hint) hh[ii * NI + j] = *(const uint2*)(hint + (int64_t)m * p.ldh + n);
+                            }
+                        }
+                    }
                 }
             }
-            if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
-            *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            const int i = i0 + ii;
+            const int m = m0 + wm * Cfg::WTM + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const int b = m / rpb;
+            const bool dead = p.valid_rows >= 0 && (m - b * rpb) >= p.valid_rows;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = nb + j * 16;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (bias) {
+                    float bb[4];
+                    unpack4(bbp[j], bb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bb[e];
+                }
+                if (EPI == VC_EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(round_bf16(v[e]));
+                } else if (EPI == VC_EPI_BIAS_RESID) {
+                    float r[4];
+                    unpack4(rr[ii * NI + j], r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(v[e]);
+                } else if (EPI == VC_EPI_GELU_MUL) {
+                    float r[4];
+                    unpack4(rr[ii * NI + j], r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(gelu_tanh_f(round_bf16(v[e]))) * r[e];
+                } else if (EPI == VC_EPI_BIAS_GATE_RESID) {
+                    float r[4], g[4];
+                    unpack4(rr[ii * NI + j], r);
+                    unpack4(gq[ii * NI + j], g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = r[e] + round_bf16(round_bf16(v[e]) * g[e]);
+                    if (hint) {
+                        float h[4];
+                        unpack4(hh[ii * NI + j], h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + round_bf16(h[e] * p.hint_scale);
+                    }
+                }
+                if (dead) v[0] = v[1] = v[2] = v[3] = 0.f;
+                *(uint2*)(C + (int64_t)m * p.ldc + n) = pack4(v);
+            }
         }
     }
 }
