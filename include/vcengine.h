@@ -150,7 +150,7 @@ int64_t vc_workspace_bytes(const vc_engine* h);
 int vc_op_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias,
                     int M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate,
                     int64_t gate_bstride, int rows_per_batch, const void* hint, int64_t ldh, float hint_scale,
-                    int tile /*0 auto, 1: 128x128, 2: 256x256*/, void* stream);
+                    int tile /*0 auto, 1: 128x128, 2: 256x256 two-stage, 3: the same with 64-bit DMA addresses, 4: ping-pong, 5: one wave per SIMD (4, 5: A readable up to the next multiple of 256 rows)*/, void* stream);
 
 /* attention() of videox_fun as called at WT.py:394-399 / 425-430.  q,k,v,out: [B, L, H, 128] with element
  * strides (batch, token, head); keys >= k_len masked (0 = none). */
