@@ -547,12 +547,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             for (int i = I0; i < I1; ++i) {
                 const int m = m0 + wr * 128 + i * 16 + (lane & 15);
                 if (m < p.M) {
-                    const bf16_t* rrow = resid + (int64_t)m * p.ldr + nb;
-                    const bf16_t* hrow = HINT ? hint + (int64_t)m * p.ldh + nb : nullptr;
+                    // 16 bytes per lane in the layout of the stores below (64 contiguous bytes per row and instruction), turned
+                    // back into the accumulator's fragment layout by the same half exchange between lane groups g and g ^ 1
+                    const bf16_t* rrow = resid + (int64_t)m * p.ldr + nst;
+                    const bf16_t* hrow = HINT ? hint + (int64_t)m * p.ldh + nst : nullptr;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        rr[(i - I0) * 4 + j] = *(const uint2*)(rrow + j * 16);
-                        if (HINT) hh[(i - I0) * 4 + j] = *(const uint2*)(hrow + j * 16);
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const uint4 L = *(const uint4*)(rrow + jp * 32);
+                        const auto x0 = __builtin_amdgcn_permlane16_swap(L.x, L.z, false, false);
+                        const auto x1 = __builtin_amdgcn_permlane16_swap(L.y, L.w, false, false);
+                        rr[(i - I0) * 4 + jp * 2] = uint2{x0[0], x1[0]};
+                        rr[(i - I0) * 4 + jp * 2 + 1] = uint2{x0[1], x1[1]};
+                        if (HINT) {
+                            const uint4 Hh = *(const uint4*)(hrow + jp * 32);
+                            const auto y0 = __builtin_amdgcn_permlane16_swap(Hh.x, Hh.z, false, false);
+                            const auto y1 = __builtin_amdgcn_permlane16_swap(Hh.y, Hh.w, false, false);
+                            hh[(i - I0) * 4 + jp * 2] = uint2{y0[0], y1[0]};
+                            hh[(i - I0) * 4 + jp * 2 + 1] = uint2{y0[1], y1[1]};
+                        }
                     }
                 }
             }
@@ -957,6 +969,8 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     const bool rows_ok = (p.M % 256 == 0) || p.a_rows_padded;
     // its epilogue stores 16 bytes per lane and holds the gate of at most two samples per tile
     bool epi_ok = p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (p.rows_per_batch == 0 || p.rows_per_batch >= 256);
+    if (p.resid) epi_ok = epi_ok && p.ldr % 8 == 0 && ((uintptr_t)p.resid & 15) == 0;        // ... and loads them the same way
+    if (p.hint) epi_ok = epi_ok && p.ldh % 8 == 0 && ((uintptr_t)p.hint & 15) == 0;
     for (int g = 1; g < p.ngroups; ++g) epi_ok = epi_ok && ((uintptr_t)p.Cg[g - 1] & 15) == 0;
     if (big && rows_ok && epi_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
         (p.tile == 0 || p.tile == 4 || p.tile == 5))
