@@ -4,7 +4,7 @@
 //   1: 16 B per lane, 16 rows x 64 B                       (after the lane-group exchange)
 //   2: 16 B per lane, 8 rows x 128 B                       (full lines, needs a transpose through LDS)
 //   3: 16 B per lane, 2 rows x 512 B
-// build: hipcc -O3 --offload-arch=gfx950 store_patterns.hip -o store_patterns ; run on the GPU box
+// build: hipcc -O3 --offload-arch=gfx950 store_patterns.hip -o store_patterns ; run on the GPU box: store_patterns [workgroups [tiles per workgroup]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
