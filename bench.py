@@ -15,7 +15,17 @@ The same line carries
                  on the launch stream) -- algorithmic FLOPs / summed duration vs the dense bf16 MFMA peak;
   breakdown    : the same for every kernel class, plus the whole-step fraction of the MFMA roofline;
   cpu_baseline : the CPU oracle (oracle/wan_oracle.py, fp32 PyTorch) timed on this box's host cores on a bounded
-                 sample (one main + one adapter block at the 14B width on a 1536-token slice) and extrapolated by FLOPs.
+                 sample (one main + one adapter block at the 14B width on the 8190 rows one rank of an 8-way run holds)
+                 and extrapolated by FLOPs;
+  teacache_on  : what a TeaCache-skipped step and a calc+store step cost on this GPU, and the steps/s that implies for the
+                 CLI's skip window as a function of the number of skipped steps (the skip RATE needs the released weights).
+
+Multi-rank start (N > 1): every rank runs in a CHILD process of a supervisor that never touches the GPU -- `python bench.py
+--gpus N` supervises all N children itself; under `python -m torch.distributed.run ... bench.py --gpus N` every torchrun worker
+supervises its own rank and the supervisors talk through torchrun's store.  A child marks "started" and "up" (communicators
+created and one probe exchange done); when the marks do not arrive in time, or the run exceeds its budget, the supervisors
+kill exactly their children and start a FRESH set with VC_SP_TRANSPORT=torch (torch.distributed's RCCL groups); if that
+fails too they exit non-zero with the tail of every rank's stderr file (bench_n<N>.rank<r>.err).
 """
 import argparse
 import json
@@ -65,51 +75,56 @@ def cpu_baseline(mk, f_step, L):
     """CPU oracle (oracle/wan_oracle.py, fp32 PyTorch: the "port") timed on this box's host cores on a BOUNDED sample of the
     same workload and extrapolated to steps/s by algorithmic FLOPs.  SURVEY 8d's protocol names one main block + one adapter
     block at full shape; at full shape one block is 42 TFLOP (minutes of CPU time), so the sample keeps the block pair and the
-    model width but cuts the token axis: one main block, then one adapter block with its after_proj (VC.py:112-125), B = 1,
-    1536 tokens.  Self-attention is 52 % of the cfg-3 step's FLOPs and only ~6 % of this sample's, and CPU attention runs below
-    CPU GEMM speed, so the extrapolated rate is OPTIMISTIC for the CPU (stated in `sample`)."""
+    model width and takes the rows ONE RANK of an 8-way sequence-parallel run holds: L/8 tokens of both CFG samples = 8190
+    rows as one sequence (B = 1): 13 TFLOP, self-attention 21 % of it (52 % of the real step; the 1536-token slice of
+    earlier rounds had 4 %).  One timed pass after a small warm-up pass (thread pool, allocator); still optimistic for the
+    CPU, whose attention runs below its GEMM rate, and labelled so."""
     import torch
     from oracle import wan_oracle as O
     d, ffn, heads = mk["dim"], mk["ffn_dim"], mk["num_heads"]
     text_len = mk.get("text_len", 512)
-    Ls = 1536 if d >= 1024 else 256
+    big = d >= 1024
+    Ls = int(os.environ.get("VC_BENCH_CPU_TOKENS", "0")) or (2 * -(-L // 8) if big else 256)
+    grid = (1, 1, Ls)                                        # RoPE positions along w (w < 1024 rows of the table)
+    if Ls > 1024:
+        w = max(x for x in range(1, 1025) if Ls % x == 0)
+        rest = Ls // w
+        hh = max(x for x in range(1, 1025) if rest % x == 0)
+        grid = (rest // hh, hh, w)
+        if grid[0] > 1024:
+            raise SystemExit(f"cpu_baseline: {Ls} tokens do not factor into a RoPE grid")
     cfg = O.Config(dim=d, ffn_dim=ffn, num_heads=heads, num_layers=1, text_len=text_len, text_dim=mk.get("text_dim", 4096))
     g = torch.Generator().manual_seed(0)
     W = {}
     for k, shp in O.state_dict_shapes(cfg).items():
         if k.startswith(("blocks.0.", "geoada_blocks.0.")):
             W[k] = torch.randn(shp, generator=g) * (0.02 if len(shp) > 1 else 1.0)
-    grid = (3, 16, Ls // 48) if Ls == 1536 else (1, 16, 16)
-    x = torch.randn(1, Ls, d, generator=g)
-    e0 = torch.randn(1, 6, d, generator=g) * 0.1
-    ctx = torch.randn(1, text_len, d, generator=g)
     freqs = O.rope_table(128)
-    f_blk = (8 * Ls * d * d + 4 * Ls * Ls * d + 4 * Ls * d * d + 4 * text_len * d * d + 4 * Ls * text_len * d + 4 * Ls * d * ffn)
-    flops = 2 * f_blk + 2 * Ls * d * d                       # main block + adapter block + after_proj
-    attn_share = 2 * 4 * Ls * Ls * d / flops
     nblk = mk["num_layers"] + (mk["num_layers"] + 1) // 2
     real_share = 2 * nblk * 4 * L * L * d / f_step
 
-    def pair():
-        y = O.attention_block(W, "blocks.0.", x, e0, [Ls], [grid], freqs, ctx, heads)
-        c = O.attention_block(W, "geoada_blocks.0.", x, e0, [Ls], [grid], freqs, ctx, heads)
-        return y, O.linear(c, W["geoada_blocks.0.after_proj.weight"], W["geoada_blocks.0.after_proj.bias"])
-    times = []
-    t_end = time.time() + 25.0
+    def pair(n, gr):
+        x = torch.randn(1, n, d, generator=g)
+        e0 = torch.randn(1, 6, d, generator=g) * 0.1
+        ctx = torch.randn(1, text_len, d, generator=g)
+        t0 = time.time()
+        y = O.attention_block(W, "blocks.0.", x, e0, [n], [gr], freqs, ctx, heads)
+        c = O.attention_block(W, "geoada_blocks.0.", x, e0, [n], [gr], freqs, ctx, heads)
+        z = O.linear(c, W["geoada_blocks.0.after_proj.weight"], W["geoada_blocks.0.after_proj.bias"])
+        return time.time() - t0, float(y.abs().mean() + z.abs().mean())
+
     with torch.no_grad():
-        for it in range(4):
-            t0 = time.time()
-            pair()
-            times.append(time.time() - t0)
-            if time.time() > t_end:
-                break
-    best = min(times[1:]) if len(times) > 1 else times[0]
+        pair(128, (1, 8, 16))                                # warm-up
+        best, _ = pair(Ls, grid)
+    f_blk = (8 * Ls * d * d + 4 * Ls * Ls * d + 4 * Ls * d * d + 4 * text_len * d * d + 4 * Ls * text_len * d + 4 * Ls * d * ffn)
+    flops = 2 * f_blk + 2 * Ls * d * d                       # main block + adapter block + after_proj
+    attn_share = 2 * 4 * Ls * Ls * d / flops
     rate = flops / best
     return {"value": rate / f_step, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32: 1 main block + 1 adapter block (+ after_proj), B=1, {Ls} tokens, d={d}: {best:.2f} s = "
-                      f"{rate / 1e12:.3f} TFLOP/s, extrapolated by FLOPs to a full step ({f_step / 1e15:.3f} PFLOP); "
-                      f"self-attention is {attn_share:.0%} of the sample's FLOPs vs {real_share:.0%} of the real step's, so this rate is "
-                      f"optimistic for the CPU",
+            "sample": f"oracle fp32: 1 main block + 1 adapter block (+ after_proj), B=1, {Ls} tokens (the rows of one rank of an "
+                      f"8-way run), d={d}: {best:.2f} s for {flops / 1e12:.2f} TFLOP = {rate / 1e12:.3f} TFLOP/s, extrapolated by "
+                      f"FLOPs to a full step ({f_step / 1e15:.3f} PFLOP); self-attention is {attn_share:.0%} of the sample's FLOPs vs "
+                      f"{real_share:.0%} of the real step's, so this rate is still optimistic for the CPU",
             "host_cpus": os.cpu_count()}
 
 
@@ -128,9 +143,8 @@ def parse_args(argv=None):
                     help="nccl (= RCCL; product: the engine's own communicators over xGMI) or gloo: a REHEARSAL of the N > 1 "
                          "launch on a box with fewer GPUs than ranks -- ranks share devices round-robin, exchange buffers are "
                          "staged through host memory; the rate it prints is not a result")
-    ap.add_argument("--teacache-steps", type=int, default=0,
-                    help="also time N sampler steps from step 0 with TeaCache on (CLI defaults: threshold 0.10, skip-start 5) "
-                         "and report them as a separate 'teacache_on' object; 0 = off (the headline metric is TeaCache-off)")
+    ap.add_argument("--no-teacache-line", action="store_true",
+                    help="skip the separate TeaCache-on measurement (forced skipped / calc + store steps, N = 1 only)")
     return ap.parse_args(argv)
 
 
@@ -143,58 +157,221 @@ def _free_port():
     return p
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Supervised multi-rank start.  Nothing in this section imports torch in the self-launch mode, and nothing in it ever touches
+# the GPU in either mode: GPU work happens in the children only, and a child is never re-executed -- a failed set is killed
+# (exactly the PIDs started here) and a FRESH set is started.
+# ----------------------------------------------------------------------------------------------------------------------
+class _LocalBoard:
+    """The supervisors' shared flags when ONE supervisor owns every rank (python bench.py --gpus N)."""
+
+    def __init__(self):
+        self.kv, self.cnt = {}, {}
+
+    def set(self, k, v):
+        self.kv[k] = v
+
+    def get(self, k, timeout=0.0):
+        return self.kv[k]
+
+    def check(self, k):
+        return k in self.kv
+
+    def add(self, k, n):
+        self.cnt[k] = self.cnt.get(k, 0) + n
+        return self.cnt[k]
+
+
+class _StoreBoard:
+    """The same over torchrun's rendezvous store (one supervisor per rank; host sockets only -- no device, no process group)."""
+
+    def __init__(self):
+        from datetime import timedelta
+        from torch.distributed import PrefixStore, rendezvous
+        store, self.rank, self.world = next(iter(rendezvous("env://", timeout=timedelta(seconds=300))))
+        self.store = PrefixStore("vc_bench_supervisor", store)
+        self._td = timedelta
+
+    def set(self, k, v):
+        self.store.set(k, v)
+
+    def get(self, k, timeout=60.0):
+        self.store.wait([k], self._td(seconds=timeout))
+        return self.store.get(k).decode()
+
+    def check(self, k):
+        return bool(self.store.check([k]))
+
+    def add(self, k, n):
+        return int(self.store.add(k, n))
+
+
+def _tail(path, n=15):
+    try:
+        with open(path, errors="replace") as f:
+            return "".join(f.readlines()[-n:])
+    except OSError:
+        return ""
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start N fresh rank
-    processes -- one per GPU, torchrun's environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as the reference's
-    `torchrun --nproc-per-node=N` of inference.sh:62-71 -- wait for them and forward rank 0's single JSON line.
-    This parent never touches the GPU (it does not even import torch); a failed rank ends the run with its exit code."""
+    """Start and supervise the rank processes (see the module docstring).  Returns the exit code.
+
+    Modes: no WORLD_SIZE in the environment -- this process owns all N children (torchrun's environment contract: RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*, as the reference's `torchrun --nproc-per-node=N` of inference.sh:62-71); WORLD_SIZE set
+    (a torchrun worker) -- it owns the child of its own rank and agrees with the other supervisors through the store.
+
+    Per attempt: children must mark "started" (VC_BENCH_START_TIMEOUT, default 300 s: a cold `import torch` takes minutes)
+    and then "up" (VC_BENCH_UP_TIMEOUT, default 90 s after the last "started": communicators created, probe exchange done);
+    the whole run has VC_BENCH_BUDGET seconds (default 560: below the driver's limit).  A stall, or a rank that dies between
+    "started" and "up", is a transport failure: attempt 2 runs fresh children with VC_SP_TRANSPORT=torch.  Any other failure,
+    or a failed attempt 2, ends the run non-zero with every rank's stderr tail."""
+    import shutil
     import subprocess
     import tempfile
     n = args.gpus
-    port = int(os.environ.get("MASTER_PORT") or _free_port())
-    procs, out0 = [], tempfile.TemporaryFile(mode="w+")
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's intra-node transport needs it on this pool
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else sys.stderr))
-    rc, deadline = 0, None
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            c = procs[r].poll()
-            if c is None:
-                continue
-            live.discard(r)
-            if c != 0 and rc == 0:
-                rc = c if c > 0 else 1
-                print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
-                deadline = time.time() + 20.0                     # peers blocked in a collective never return by themselves
-        if deadline is not None and time.time() > deadline:
-            for r in live:
-                procs[r].kill()                                   # exactly the children started above
-            deadline = None
-        time.sleep(0.05)
-    out0.seek(0)
-    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
-    if rc == 0 and len(lines) != 1:
-        print(f"bench.py: rank 0 printed {len(lines)} lines, expected exactly one", file=sys.stderr)
-        rc = 1
-    if rc == 0:
-        sys.stdout.write(lines[0] + "\n")
+    t_begin = time.time()
+    budget = float(os.environ.get("VC_BENCH_BUDGET", "560"))
+    t_start_lim = float(os.environ.get("VC_BENCH_START_TIMEOUT", "300"))
+    t_up_lim = float(os.environ.get("VC_BENCH_UP_TIMEOUT", "90"))
+    grace = float(os.environ.get("VC_BENCH_KILL_GRACE", "10"))
+    log_dir = os.environ.get("VC_BENCH_LOG_DIR") or os.getcwd()
+    child_cmd = os.environ.get("VC_BENCH_TEST_CHILD")              # tests: a stand-in rank program
+    child_argv = [sys.executable, child_cmd] if child_cmd else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    under_launcher = "WORLD_SIZE" in os.environ
+    if under_launcher:
+        if int(os.environ["WORLD_SIZE"]) != n:
+            print(f"bench.py: --gpus {n} but WORLD_SIZE={os.environ['WORLD_SIZE']}", file=sys.stderr)
+            return 2
+        board = _StoreBoard()
+        mine = {board.rank: int(os.environ.get("LOCAL_RANK", board.rank))}
+        me = board.rank
+    else:
+        board = _LocalBoard()
+        mine = {r: r for r in range(n)}
+        me = 0
+    status_dir = tempfile.mkdtemp(prefix="vc_bench_")
+    err_paths = {r: os.path.join(log_dir, f"bench_n{n}.rank{r}.err") for r in mine}
+    for pth in err_paths.values():
+        open(pth, "w").close()
+    rc_final, line = 1, None
+    attempts = [None, "torch"] if os.environ.get("VC_SP_TRANSPORT") is None else [os.environ["VC_SP_TRANSPORT"]]
+    try:
+        for a, transport in enumerate(attempts):
+            # ---- a fresh rendezvous port for the children, agreed through the board
+            if me == 0:
+                board.set(f"port{a}", str(_free_port()))
+            port = int(board.get(f"port{a}", timeout=120.0))
+            procs, outs = {}, {}
+            for r, local in mine.items():
+                env = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+                env.update(RANK=str(r), LOCAL_RANK=str(local), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VC_BENCH_CHILD="1",
+                           VC_BENCH_STATUS_DIR=status_dir, VC_BENCH_ATTEMPT=str(a))
+                # dmabuf IPC (versecrafter_amd.dist.ensure_ipc_env: the hosts of this pool refuse the legacy IPC mode)
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                if transport is not None:
+                    env["VC_SP_TRANSPORT"] = transport
+                with open(err_paths[r], "a") as ef:
+                    ef.write(f"==== attempt {a} (transport {transport or 'default: engine-owned RCCL'}) rank {r} port {port}\n")
+                outs[r] = open(os.path.join(status_dir, f"rank{r}.a{a}.out"), "w+")
+                procs[r] = subprocess.Popen(child_argv, env=env, stdout=outs[r], stderr=open(err_paths[r], "a"))
+            t_spawn = time.time()
+            t_all_started = None
+            marked = {r: set() for r in mine}
+            live, why, kind = set(mine), None, None
+            fail_seen_at = None
+            while True:
+                now = time.time()
+                exited = {r: procs[r].poll() for r in sorted(live)}
+                for r in mine:                                     # marks first: they classify an exit seen in the same pass
+                    for m in ("started", "up"):
+                        if m not in marked[r] and os.path.exists(os.path.join(status_dir, f"rank{r}.a{a}.{m}")):
+                            marked[r].add(m)
+                            board.add(f"{m}{a}", 1)
+                for r, c in exited.items():
+                    if c is None:
+                        continue
+                    live.discard(r)
+                    if c == 0:
+                        board.add(f"done{a}", 1)
+                    elif not board.check(f"fail{a}"):
+                        in_bringup = "started" in marked[r] and "up" not in marked[r]
+                        board.set(f"fail{a}", f"{'transport' if in_bringup else 'rank'}: rank {r} exited with code {c}")
+                n_started, n_up = board.add(f"started{a}", 0), board.add(f"up{a}", 0)
+                if n_started >= n and t_all_started is None:
+                    t_all_started = now
+                if board.check(f"fail{a}"):
+                    if fail_seen_at is None:
+                        fail_seen_at = now
+                        why = board.get(f"fail{a}")
+                        kind = why.split(":", 1)[0]
+                        print(f"bench.py: attempt {a}: {why}; stopping this set of ranks", file=sys.stderr)
+                    if not live or now - fail_seen_at > grace:     # peers blocked in a collective never return by themselves
+                        break
+                elif board.add(f"done{a}", 0) >= n:
+                    break
+                elif n_started < n and now - t_spawn > t_start_lim:
+                    board.set(f"fail{a}", f"stall: {n_started} of {n} ranks started within {t_start_lim:.0f} s")
+                elif n_started >= n and n_up < n and now - t_all_started > t_up_lim:
+                    board.set(f"fail{a}", f"stall: {n_up} of {n} ranks brought their communicators up within {t_up_lim:.0f} s "
+                                          f"of starting")
+                elif now - t_begin > budget:
+                    board.set(f"fail{a}", f"stall: over the run budget of {budget:.0f} s")
+                time.sleep(0.1)
+            for r in live:                                         # exactly the children started above
+                procs[r].kill()
+            for r in mine:
+                procs[r].wait()
+            # nobody starts the next set before every supervisor has ended this one
+            board.add(f"end{a}", len(mine))
+            t_w = time.time()
+            while board.add(f"end{a}", 0) < n and time.time() - t_w < 60:
+                time.sleep(0.1)
+            if why is None:
+                rc_final = 0
+                if 0 in mine:
+                    outs[0].seek(0)
+                    lines = [ln for ln in outs[0].read().splitlines() if ln.strip()]
+                    if len(lines) != 1:
+                        print(f"bench.py: rank 0 printed {len(lines)} lines, expected exactly one", file=sys.stderr)
+                        rc_final = 1
+                    else:
+                        line = lines[0]
+                break
+            retry = kind in ("stall", "transport") and a + 1 < len(attempts) and time.time() - t_begin < budget
+            if not retry:
+                break
+            print(f"bench.py: starting a fresh set of ranks with VC_SP_TRANSPORT={attempts[a + 1]}", file=sys.stderr)
+        if rc_final != 0:
+            for r in sorted(mine):
+                print(f"---- rank {r} stderr tail ({err_paths[r]}) ----\n{_tail(err_paths[r])}", file=sys.stderr)
+    finally:
+        shutil.rmtree(status_dir, ignore_errors=True)
+    if rc_final == 0 and line is not None:
+        sys.stdout.write(line + "\n")
         sys.stdout.flush()
-    return rc
+    return rc_final
+
+
+def _mark(name):
+    """Child side of the supervisor's protocol: an empty marker file (no-op without a supervisor)."""
+    d = os.environ.get("VC_BENCH_STATUS_DIR")
+    if d:
+        open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}.a{os.environ.get('VC_BENCH_ATTEMPT', '0')}.{name}"), "w").close()
 
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and os.environ.get("VC_BENCH_CHILD") != "1":
         sys.exit(launch_ranks(args))
     run_rank(args)
 
 
 def run_rank(args):
+    # dmabuf IPC before the HIP runtime starts (versecrafter_amd.dist.ensure_ipc_env says why)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -215,11 +392,12 @@ def run_rank(args):
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    _mark("started")
     use_dist = world > 1 or os.environ.get("VC_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the N>1 plumbing at N=1
     if use_dist:
         # host-side group (gloo): rendezvous, barrier, max-over-ranks of the time, shipping the ncclUniqueIds.  The data
         # path's RCCL communicators belong to the engine (vc_sp_init_rccl); torch's own "nccl" backend is registered for
-        # CUDA tensors so that SequenceParallel recognises an RCCL-capable world, but no torch collective runs on it.
+        # CUDA tensors (the CFG split's gather of the noise prediction, and the torch-transport fallback, run on it).
         dist.init_process_group("gloo" if rehearsal else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
@@ -231,24 +409,60 @@ def run_rank(args):
     T, h, w = (frames - 1) // 4 + 1, height // 8, width // 8
     L = T * (h // 2) * (w // 2)
     text_dim = mk.get("text_dim", 4096)
+    NL, NA = mk["num_layers"], (mk["num_layers"] + 1) // 2
+    f_step = step_flops(mk["dim"], mk["ffn_dim"], NL, NA, L, 2, mk.get("text_len", 512), text_dim)
 
-    # ---- model: random weights of the named architecture, identical on every rank (seed 0) ----
     torch.manual_seed(0)
     model = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16, **mk)
-    model.init_weights(zero_init_outputs=False)
-    # N = 2: the two samples of the CFG pair are independent units -- one per rank, no data-path collective, only the noise
-    # prediction is all-gathered.  N >= 4: Ulysses over all ranks.  --cfg-degree overrides.
-    cfg_degree = args.cfg_degree if args.cfg_degree else (2 if world == 2 else 1)
-    if world % cfg_degree:
-        raise SystemExit(f"--cfg-degree {cfg_degree} does not divide --gpus {world}")
-    sp_degree = world // cfg_degree
+
+    # ---- layouts: (cfg_degree, sp_degree).  N = 2 measures BOTH ways of using two GPUs in this one run -- Ulysses over the two
+    # ranks (north_star's curve) and one CFG sample per rank (no data-path collective: DESIGN.md 6); the faster one is the
+    # headline, the other goes under "alt".  N >= 4: Ulysses over all ranks.  --cfg-degree pins one layout.
+    if args.cfg_degree:
+        if world % args.cfg_degree:
+            raise SystemExit(f"--cfg-degree {args.cfg_degree} does not divide --gpus {world}")
+        layouts = [(args.cfg_degree, world // args.cfg_degree)]
+    elif world == 2 and not rehearsal:
+        layouts = [(1, 2), (2, 1)]
+    else:
+        layouts = [(1, world)]
+    groups, sps, observed = {}, {}, {}
+    vdist = None
     if use_dist:
         from versecrafter_amd import dist as vdist
-        sp_group, bp_group = vdist.make_groups(sp_degree, cfg_degree)
-        if sp_degree == 1 and cfg_degree > 1:
-            model.enable_multi_gpus_inference()                       # batch-parallel only
+        for lay in layouts:                                            # process groups of every layout, created once
+            groups[lay] = vdist.make_groups(lay[1], lay[0])
+
+    def configure(lay):
+        """Point the model at one layout's groups (communicators are created on the first use of a layout only)."""
+        if not use_dist:
+            return
+        sp_group, bp_group = groups[lay]
+        vdist.use_groups(sp_group, bp_group)
+        if lay[1] == 1 and lay[0] > 1:
+            model.enable_multi_gpus_inference()                        # batch-parallel only: no sequence exchange
         else:
-            model.enable_multi_gpus_inference(vdist.SequenceParallel(sp_group, force_exchange=(world == 1)))
+            if lay not in sps:
+                sps[lay] = vdist.SequenceParallel(sp_group, force_exchange=(world == 1))
+            model.enable_multi_gpus_inference(sps[lay])
+
+    # ---- bring-up, BEFORE any weight exists: every layout's communicators are created and each carries one probe collective;
+    # what the transports report about their size is kept for the JSON line.  Timed order = `layouts`; bring-up runs it in
+    # reverse so that the model ends up configured for the first one.
+    for lay in reversed(layouts):
+        configure(lay)
+        obs = {}
+        if use_dist:
+            transport = model.attach_communicators()
+            if lay[1] > 1 or world == 1:
+                obs["sp"] = model._sp.probe(dev) if hasattr(model._sp, "probe") else {"ranks": 0, "transport": transport}
+            if lay[0] > 1:
+                obs["cfg"] = model._bp.observed_ranks(dev)
+        observed[lay] = obs
+    _mark("up")
+
+    # ---- random weights of the named architecture, identical on every rank (seed 0) ----
+    model.init_weights(zero_init_outputs=False)
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
     pipe = WanVerseCrafterPipeline(transformer=model, scheduler=scheduler)
     pipe._guidance_scale = 5.0
@@ -279,76 +493,104 @@ def run_rank(args):
         if use_dist:
             dist.all_reduce(torch.zeros(1))                        # ... and so has every other rank's (host-side, gloo)
 
-    lat = run_steps(latents, 0, args.warmup)
-    barrier()
-    if not args.no_profile:
-        model.profile_enable(True)
-    t0 = time.perf_counter()
-    lat = run_steps(lat, args.warmup, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = None
-    if not args.no_profile:
-        prof = model.profile_read()
-        model.profile_enable(False)
-    finite = bool(torch.isfinite(lat.float()).all().item())
-    tea = None
-    if args.teacache_steps > 0:
-        # TeaCache-on is a separate line.  With random weights the gate's statistics are not those of the
-        # released checkpoint -- the count of skipped steps is reported next to the rate.
-        coeff_14b = [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02]   # CLI.py:305-313
-        model.enable_teacache(coeff_14b, args.num_inference_steps, 0.10, num_skip_start_steps=5, offload=False)
+    def timed(lay):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks."""
+        configure(lay)
         scheduler.set_timesteps(args.num_inference_steps, device=dev, shift=16)
-        n = min(args.teacache_steps, args.num_inference_steps)
-        skipped = 0
+        lat = run_steps(latents, 0, args.warmup)
         barrier()
-        t1 = time.perf_counter()
-        lt = latents
-        for i in range(n):
-            lt = pipe.denoise_step(i, ts[i], lt, embeds, geoada_in, seq_len, True, 1.0)
-            skipped += 0 if model.should_calc else 1
+        if not args.no_profile:
+            model.profile_enable(True)
+        t0 = time.perf_counter()
+        lat = run_steps(lat, args.warmup, args.steps)
         barrier()
-        el = time.perf_counter() - t1
-        model.disable_teacache()
-        tea = {"value": n / el, "unit": "denoise-steps/s", "steps": n, "skipped_steps": skipped, "threshold": 0.10,
-               "num_skip_start_steps": 5, "note": "random weights: gate statistics differ from the released checkpoint"}
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    rccl_ranks = model.sp_comm_ranks()
-    if cfg_degree > 1 and not rehearsal:
-        rccl_ranks = max(rccl_ranks, 1) * cfg_degree      # + the batch-parallel gather on torch's nccl (= RCCL) groups
+        elapsed = time.perf_counter() - t0
+        prof = None
+        if not args.no_profile:
+            prof = model.profile_read()
+            model.profile_enable(False)
+        finite = bool(torch.isfinite(lat.float()).all().item())
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            ff = torch.tensor([1.0 if finite else 0.0])
+            dist.all_reduce(ff, op=dist.ReduceOp.MIN)
+            finite = bool(ff.item() > 0)
+        # what the transports of this layout say about their size NOW, after they carried the timed steps
+        obs = dict(observed.get(lay, {}))
+        if use_dist and (lay[1] > 1 or world == 1) and model._sp is not None:
+            obs["sp"] = dict(obs.get("sp", {}), ranks=model._sp.observed_ranks(_lib_handle(model), dev))
+        return {"layout": lay, "elapsed": elapsed, "prof": prof, "finite": finite, "observed": obs,
+                "transport": getattr(model._sp, "transport", "none") if lay[1] > 1 or (world == 1 and use_dist) else "none"}
+
+    def _lib_handle(m):
+        return m._engine_handle()
+
+    results = [timed(lay) for lay in layouts]
+
+    tea = None
+    if world == 1 and not use_dist and not args.no_teacache_line:
+        tea = teacache_line(args, model, pipe, scheduler, latents, embeds, geoada_in, seq_len, ts, dev)
 
     if rank == 0:
-        NL, NA = mk["num_layers"], (mk["num_layers"] + 1) // 2
-        f_step = step_flops(mk["dim"], mk["ffn_dim"], NL, NA, L, 2, mk.get("text_len", 512), text_dim)
-        sps = args.steps / elapsed
+        def line_of(res):
+            cfgd, spd = res["layout"]
+            sps_ = args.steps / res["elapsed"]
+            obs = res["observed"]
+            sp_ranks = int(obs.get("sp", {}).get("ranks", 0) or 0)
+            cfg_ranks = int(obs.get("cfg", {}).get("ranks", 0) or 0)
+            on_rccl = (not rehearsal) and use_dist
+            rccl_ranks = 0
+            if on_rccl:
+                rccl_ranks = (sp_ranks if spd > 1 or world == 1 else 1) * (cfg_ranks if cfgd > 1 else 1)
+                if spd == 1 and cfgd == 1 and world > 1:
+                    rccl_ranks = 0
+            if spd > 1 or (world == 1 and use_dist):
+                tr = ("gloo + host-staged buffers (REHEARSAL of the launch, not a result)" if rehearsal else
+                      "engine-owned RCCL communicators, one per stream lane" if res["transport"] == "rccl" else
+                      "torch.distributed RCCL process groups, one per stream lane (engine-owned communicators unavailable)")
+                if cfgd > 1:
+                    tr += "; the CFG pair split over rank groups, noise prediction all-gathered over torch.distributed's RCCL group"
+            elif cfgd > 1:
+                tr = ("gloo (REHEARSAL)" if rehearsal else
+                      "one CFG sample per rank, no data-path collective; the noise prediction is all-gathered over "
+                      "torch.distributed's RCCL group")
+            else:
+                tr = "none (single rank)"
+            out = {"value": sps_, "ms_per_step": 1000.0 * res["elapsed"] / args.steps,
+                   "parallelism": f"ulysses-sp{spd}" if cfgd == 1 else f"cfg{cfgd} x ulysses-sp{spd}",
+                   "cfg": "batched pair" if cfgd == 1 else "one sample per rank",
+                   "step_mfma_frac": f_step * sps_ / (world * PEAK_BF16_TFLOPS * 1e12),
+                   "outputs_finite": res["finite"],
+                   # ranks counted BY the transports (ncclCommCount of the engine's communicator after the timed steps; the sum
+                   # of an all-reduce of ones on the CFG group's RCCL backend): 0 = no RCCL collective ran
+                   "rccl_ranks": rccl_ranks, "rccl_observed": obs, "transport": tr}
+            return out
+        lines = [line_of(r) for r in results]
+        best = max(range(len(lines)), key=lambda i: lines[i]["value"])
+        head, res = lines[best], results[best]
+        sps = head["value"]
         out = {
             "metric": "denoise-steps/sec Wan2.1-14B+GeoAdapter 81fx480p" if args.workload == "wan14b-81f-480x832"
                       else f"denoise-steps/sec {args.workload}",
             "value": sps, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights seed 0, inputs seed 2025)",
             "config": {"workload": args.workload, "latent": [16, T, h, w], "tokens": L, "global_batch": 2,
-                       "cfg": "batched pair", "guidance_scale": 5.0, "sampler": "UniPC shift 16",
-                       "teacache": "off",
-                       "parallelism": f"ulysses-sp{world}" if cfg_degree == 1 else f"cfg{cfg_degree} x ulysses-sp{sp_degree}",
-                       "pflop_per_step": f_step / 1e15},
-            "step_mfma_frac": f_step * sps / (world * PEAK_BF16_TFLOPS * 1e12),
+                       "cfg": head["cfg"], "guidance_scale": 5.0, "sampler": "UniPC shift 16",
+                       "teacache": "off", "parallelism": head["parallelism"], "pflop_per_step": f_step / 1e15},
+            "step_mfma_frac": head["step_mfma_frac"],
             # the same with the output-neutral work the engine skips taken out of the numerator (see skipped_flops)
             "step_mfma_frac_executed": (f_step - skipped_flops(mk["dim"], NL, NA, L, 2, (n_un, n_co), mk.get("text_len", 512),
                                                                text_dim)) * sps / (world * PEAK_BF16_TFLOPS * 1e12),
-            "outputs_finite": finite,
-            # world size the engine's own RCCL communicator reports after init (ncclCommCount); 0 = no RCCL exchange ran
-            "rccl_ranks": rccl_ranks,
-            "transport": ("none (single rank)" if not use_dist else
-                          "gloo + host-staged buffers (REHEARSAL of the launch, not a result)" if rehearsal else
-                          "one CFG sample per rank, no data-path collective; the noise prediction is all-gathered over "
-                          "torch.distributed's RCCL group" if sp_degree == 1 else
-                          "engine-owned RCCL communicators, one per stream lane" if rccl_ranks else
-                          "torch.distributed RCCL process groups, one per stream lane (engine-owned communicators unavailable)"),
+            "outputs_finite": head["outputs_finite"],
+            "rccl_ranks": head["rccl_ranks"], "rccl_observed": head["rccl_observed"], "transport": head["transport"],
         }
+        if len(lines) > 1:
+            # the other layout of the same run, each timed over the same K steps after the same W warm-up steps
+            out["alt"] = [dict(ln, note="not the headline: slower layout of this run") for i, ln in enumerate(lines) if i != best]
+        prof = res["prof"]
         if prof is not None:
             bd = {}
             for k, v in prof.items():
@@ -390,6 +632,48 @@ def run_rank(args):
     if use_dist:
         dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
+
+
+def teacache_line(args, model, pipe, scheduler, latents, embeds, geoada_in, seq_len, ts, dev):
+    """SURVEY 8d's separate TeaCache-on line, in the only form random weights can fill (the gate's statistics -- whether a step
+    IS skipped -- belong to the released checkpoint; with random weights the time embedding's relative L1 change never drops
+    under the CLI's threshold 0.10 and nothing is skipped: profiles/r02_v5_bench_teacache_50steps.json).  What a skipped step
+    and a calc + store step COST is a property of the engine: the gate is forced (calc, skip, skip, calc, skip, calc) and every
+    step is timed with the device drained on both sides; the implied rate over the CLI's window (50 steps, the first 5 always
+    computed: CLI.py:104-116) is listed as a function of the number of skipped steps."""
+    import torch
+    coeff_14b = [8.10705460e+03, 2.13393892e+03, -3.72934672e+02, 1.66203073e+01, -4.17769401e-02]   # CLI.py:305-313
+    n_steps = args.num_inference_steps
+    model.enable_teacache(coeff_14b, n_steps, 0.10, num_skip_start_steps=5, offload=False)
+    scheduler.set_timesteps(n_steps, device=dev, shift=16)
+    forced = [True, False, False, True, False, True]
+    it = iter(forced)
+    tc = model.teacache
+
+    def gate(e0):
+        tc.previous_modulated_input = e0
+        tc.should_calc = next(it)
+        return tc.should_calc
+    tc.gate = gate
+    calc_ms, skip_ms = [], []
+    lt = latents
+    for i, calc in enumerate(forced):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lt = pipe.denoise_step(i, ts[i], lt, embeds, geoada_in, seq_len, True, 1.0)
+        torch.cuda.synchronize()
+        (calc_ms if calc else skip_ms).append(1000.0 * (time.perf_counter() - t0))
+    model.disable_teacache()
+    finite = bool(torch.isfinite(lt.float()).all().item())
+    c = sorted(calc_ms[1:])[len(calc_ms[1:]) // 2]          # the first calc + store step also allocates the residual slot
+    k = sorted(skip_ms)[len(skip_ms) // 2]
+    window = n_steps - 5
+    implied = {str(j): n_steps / (((n_steps - j) * c + j * k) / 1000.0) for j in (0, 5, 10, 15, 20, 25, 30) if j <= window}
+    return {"calc_step_ms": c, "skipped_step_ms": k, "calc_steps_ms_all": calc_ms, "skipped_steps_ms_all": skip_ms,
+            "outputs_finite": finite, "unit": "denoise-steps/s", "num_inference_steps": n_steps, "threshold": 0.10,
+            "num_skip_start_steps": 5, "implied_steps_per_s_by_skipped_steps": implied,
+            "note": "gate forced (calc, skip, skip, calc, skip, calc): the cost of each step type on this GPU; how MANY steps the "
+                    "gate skips needs the released weights (random weights skip none at threshold 0.10)"}
 
 
 if __name__ == "__main__":

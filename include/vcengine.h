@@ -94,6 +94,7 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
  * enqueues every exchange on the HIP stream of the chain that needs it, so the two chains overlap each other's exchanges
  * and nothing calls back into the host on the step path.  librccl.so.1 is bound with dlopen at the first of these calls (the
  * instance already loaded into the process is reused; VC_RCCL_LIB overrides the path).
+ *   vc_rccl_available : binds librccl only.
  *   vc_rccl_unique_id : rank 0 fills out[128] (ncclGetUniqueId); the host ships the bytes to every rank (any side channel).
  *   vc_sp_init_rccl   : unique_ids = n_ids x 128 bytes, n_ids must be 2 (chain 0, chain 1); every rank of the world must
  *                       call it (ncclCommInitRank is a rendezvous).  flags: VC_SP_FORCE_EXCHANGE runs the exchange path
@@ -103,6 +104,8 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
  *   vc_sp_all_to_all / vc_sp_all_gather : the engine's collectives in isolation (tests): byte buffers, chain 0 or 1. */
 #define VC_RCCL_UNIQUE_ID_BYTES 128
 #define VC_SP_FORCE_EXCHANGE 1u
+int vc_rccl_available(void);      /* 0 when librccl can be bound on this rank (no device work): lets the ranks AGREE, before the
+                                   * first step that can fail on one side only, whether the engine-owned transport is usable */
 int vc_rccl_unique_id(void* out, int nbytes);
 int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, int n_ids, uint32_t flags);
 int vc_sp_comm_ranks(const vc_engine* h);
@@ -157,6 +160,12 @@ int vc_op_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void
 int vc_op_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                     const int64_t* o_strides, int k_len, float scale, void* stream);
+
+/* vc_op_attention with the MFMA shape of the pipelined kernel forced (tests / A-B tools): variant 32 = v_mfma_f32_32x32x16_bf16,
+ * 16 = v_mfma_f32_16x16x32_bf16, 0 = the library's default.  Same contract and tolerance as vc_op_attention. */
+int vc_op_attention_variant(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                            const int64_t* o_strides, int k_len, float scale, int variant, void* stream);
 
 /* The same attention on the Ulysses receive layout (token axis in segments of seg_len tokens, one per source rank):
  * strides are {batch, token within a segment, head, segment}; token t = (t / seg_len, t % seg_len).  Lq = Lk = L. */

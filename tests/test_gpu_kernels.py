@@ -295,6 +295,44 @@ def test_attention_large_logits_rescale(ops):
     assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="rescale")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,k_len", [(2, 2, 200, 200, 150), (1, 3, 130, 1000, 0), (1, 1, 64, 520, 513), (1, 2, 300, 2304, 0),
+                                             (2, 1, 517, 2500, 2431), (1, 1, 256, 4160, 4097), (1, 2, 129, 64, 64)])
+def test_attention_mfma16_variant(ops, B, H, Lq, Lk, k_len):
+    """The v_mfma_f32_16x16x32_bf16 form of the pipelined kernel (attention16.hip; round-3 MFMA-shape A/B) against the oracle at
+    the same bound as the 32x32x16 form: 4- and 8-wave workgroups (Lk < / >= 2048), ragged query counts, partial last key tile,
+    key-length mask inside the last tile, odd and even tile counts (the pipeline's three tails)."""
+    rs = np.random.RandomState(Lq + Lk + 16)
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for L in (Lq, Lk, Lk))
+    want = O.attention(q.float(), k.float(), v.float(), None if k_len == 0 else [k_len] * B)
+    got = ops.attention(dev(q), dev(k), dev(v), k_len=k_len, variant=16)
+    ref32 = ops.attention(dev(q), dev(k), dev(v), k_len=k_len, variant=32)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="attention mfma16")
+    assert rel_l2(got, want) < 6e-3
+    assert rel_l2(got, ref32.float().cpu()) < 6e-3
+
+
+def test_attention_mfma16_rescale_and_packed_layout(ops):
+    """Forced online-softmax rescale (cdna_hip_programming.md rule 26) and the engine's strided q|k|v view, 16x16x32 form."""
+    rs = np.random.RandomState(5)
+    B, H, L = 1, 1, 320
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for _ in range(3))
+    k[0, 300, 0] = q[0, 7, 0] * 4.0
+    k[0, 10, 0] = q[0, 100, 0] * 3.0
+    k[0, 200, 0] = q[0, 23, 0] * 4.0         # a row of the second 16-query block of its wave
+    want = O.attention(q.float(), k.float(), v.float(), None)
+    got = ops.attention(dev(q), dev(k), dev(v), variant=16)
+    assert_bf16_close(got, want, ulps=3.0, atol=4e-3, what="rescale mfma16")
+    B, L, H = 2, 96, 2
+    d = H * 128
+    qkv = bf(rs_randn(rs, B, L, 3 * d))
+    g = dev(qkv)
+    q, k, v = (g[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128)) for i in range(3))
+    got = ops.attention(q, k, v, k_len=90, variant=16)
+    qc, kc, vc = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128)).float() for i in range(3))
+    assert_bf16_close(got, O.attention(qc, kc, vc, [90, 90]), ulps=3.0, atol=4e-3, what="packed mfma16")
+
+
 # ----------------------------------------------------------------------------------------- row kernels
 @pytest.mark.parametrize("dim", [256, 1536, 5120])
 def test_layernorm_modulate(ops, dim):

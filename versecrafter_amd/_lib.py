@@ -53,6 +53,7 @@ SYMBOLS = {
     "vc_missing_weights": (_I, [_P]),
     "vc_set_rope_table": (_I, [_P, C.POINTER(C.c_double), _I, _I]),
     "vc_sp_init": (_I, [_P, _I, _I, ALL_TO_ALL_FN, ALL_GATHER_FN, _P]),
+    "vc_rccl_available": (_I, []),
     "vc_rccl_unique_id": (_I, [_P, _I]),
     "vc_sp_init_rccl": (_I, [_P, _I, _I, _P, _I, C.c_uint32]),
     "vc_sp_comm_ranks": (_I, [_P]),
@@ -69,6 +70,8 @@ SYMBOLS = {
     "vc_op_gemm_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _L, _F, _I, _P]),
     "vc_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                              C.POINTER(_L), _I, _F, _P]),
+    "vc_op_attention_variant": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
+                                     C.POINTER(_L), _I, _F, _I, _P]),
     "vc_op_attention_segmented": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                        C.POINTER(_L), _I, _I, _F, _P]),
     "vc_op_attention_padmerge": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),

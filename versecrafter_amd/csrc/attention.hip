@@ -44,6 +44,9 @@ namespace {
 #ifndef VC_ATTN_ABLATE
 #define VC_ATTN_ABLATE 0
 #endif
+#ifndef VC_ATTN_DEFAULT_SHAPE
+#define VC_ATTN_DEFAULT_SHAPE 32    // 32: v_mfma_f32_32x32x16_bf16 (this file); 16: v_mfma_f32_16x16x32_bf16 (attention16.hip)
+#endif
 #ifndef VC_ATTN_QK_INTERLEAVE
 #define VC_ATTN_QK_INTERLEAVE 0
 #endif
@@ -652,6 +655,10 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
         return launch_attn_pipe<false, 4, true>(p, stream);
     }
     if (p.seg_len == 0 && p.Lk <= SHORT_MAX_TILES * KT && p.Lq >= 1024) return launch_attn_short<false>(p, (p.Lk + KT - 1) / KT, stream);
+    // MFMA shape of the pipelined kernel (round 3 A/B): variant 16 / 32 force one, 0 takes VC_ATTN_DEFAULT_SHAPE
+    if (p.variant != 0 && p.variant != 16 && p.variant != 32) return VC_E_INVALID;
+    if ((p.variant ? p.variant : VC_ATTN_DEFAULT_SHAPE) == 16 && p.seg_len == 0 && (p.o_ts | p.o_hs | p.o_bs) % 8 == 0)
+        return vc_launch_attention_mfma16(p, stream);
     if (p.Lk >= 2048) return p.seg_len > 0 ? launch_attn_pipe<true, 8>(p, stream) : launch_attn_pipe<false, 8>(p, stream);
     return p.seg_len > 0 ? launch_attn_pipe<true, 4>(p, stream) : launch_attn_pipe<false, 4>(p, stream);
 }

@@ -702,6 +702,12 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
     return VC_OK;
 }
 
+int vc_rccl_available(void) {
+    const int r = vc_comm_available();
+    if (r != VC_OK) return fail(nullptr, r, "vc_rccl_available: %s", vc_comm_error());
+    return VC_OK;
+}
+
 int vc_rccl_unique_id(void* out, int nbytes) {
     if (!out || nbytes < VC_RCCL_UNIQUE_ID_BYTES) return fail(nullptr, VC_E_INVALID, "vc_rccl_unique_id: need %d bytes", VC_RCCL_UNIQUE_ID_BYTES);
     int r = vc_comm_unique_id(out);
@@ -1211,6 +1217,20 @@ int vc_op_attention(const void* q, const void* k, const void* v, void* out, int 
     a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
     a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale;
+    return vc_launch_attention(a, (hipStream_t)stream);
+}
+
+int vc_op_attention_variant(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                            const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, int k_len, float scale,
+                            int variant, void* stream) {
+    if (!qs || !ks || !vs || !os) return VC_E_INVALID;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale; a.variant = variant;
     return vc_launch_attention(a, (hipStream_t)stream);
 }
 

@@ -97,6 +97,17 @@ int nfail(const Api* a, const char* what, ncclResult_t r) {
         if (_r != ncclSuccess) return nfail(a, #expr, _r);        \
     } while (0)
 
+// the same inside an open ncclGroupStart: the group is closed before the error is returned -- an unclosed group would
+// silently queue every later collective of this thread, a torch.distributed fallback's included
+#define NCHK_IN_GROUP(a, expr)                                    \
+    do {                                                          \
+        ncclResult_t _r = (expr);                                 \
+        if (_r != ncclSuccess) {                                  \
+            (void)(a)->GroupEnd();                                \
+            return nfail(a, #expr, _r);                           \
+        }                                                         \
+    } while (0)
+
 }  // namespace
 
 struct VcComm {
@@ -106,6 +117,8 @@ struct VcComm {
 };
 
 const char* vc_comm_error() { return t_err.c_str(); }
+
+int vc_comm_available() { return api() ? VC_OK : VC_E_UNSUPPORTED; }
 
 int vc_comm_unique_id(void* out128) {
     const Api* a = api();
@@ -167,8 +180,8 @@ int vc_comm_all_to_all(VcComm* c, const void* send, void* recv, int64_t bytes_pe
     }
     NCHK(a, a->GroupStart());
     for (int r = 0; r < c->world; ++r) {
-        NCHK(a, a->Send((const char*)send + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
-        NCHK(a, a->Recv((char*)recv + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+        NCHK_IN_GROUP(a, a->Send((const char*)send + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+        NCHK_IN_GROUP(a, a->Recv((char*)recv + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
     }
     NCHK(a, a->GroupEnd());
     return VC_OK;
@@ -188,11 +201,11 @@ int vc_comm_all_to_all_n(VcComm* c, const void* send, void* recv, int64_t bytes_
         const char* sj = (const char*)send + j * slab;
         char* rj = (char*)recv + j * slab;
         if (!c->grouped_p2p) {
-            NCHK(a, a->AllToAll(sj, rj, cnt, ncclBfloat16, c->comm, s));
+            NCHK_IN_GROUP(a, a->AllToAll(sj, rj, cnt, ncclBfloat16, c->comm, s));
         } else {
             for (int r = 0; r < c->world; ++r) {
-                NCHK(a, a->Send(sj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
-                NCHK(a, a->Recv(rj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+                NCHK_IN_GROUP(a, a->Send(sj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
+                NCHK_IN_GROUP(a, a->Recv(rj + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, r, c->comm, s));
             }
         }
     }

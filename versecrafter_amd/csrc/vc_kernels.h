@@ -58,8 +58,12 @@ struct VcAttnParams {
     // folded into one key with multiplicity Lk - pad_from[b]  (pad_merge != 0; B <= 8; pad_from[b] < 0 or >= Lk-1: nothing to fold)
     int pad_merge;
     int pad_from[8];
+    // kernel selection for tests / tuning (a launch parameter, no global state): 0 = the launcher's choice, 32 = the
+    // v_mfma_f32_32x32x16_bf16 pipelined kernel, 16 = the v_mfma_f32_16x16x32_bf16 one (attention16.hip; plain layout only)
+    int variant;
 };
 int vc_launch_attention(const VcAttnParams& p, hipStream_t stream);
+int vc_launch_attention_mfma16(const VcAttnParams& p, hipStream_t stream);     // attention16.hip
 
 // ---- row kernels --------------------------------------------------------------------------
 // y = LN(x) * (1 + scale[b]) + shift[b]        (mode 0, WT.py:591,603; head WT.py:643)
@@ -114,6 +118,7 @@ int vc_launch_delay(double usec, hipStream_t st);
 // ---- RCCL transport of the Ulysses exchange (sp_rccl.hip); librccl is bound with dlopen at first use ----
 #define VC_RCCL_UNIQUE_ID_BYTES 128
 struct VcComm;
+int vc_comm_available();                 // librccl can be bound (dlopen + every symbol) -- no device work
 int vc_comm_unique_id(void* out128);
 int vc_comm_create(VcComm** out, const void* id128, int world, int rank);   // blocks until all ranks have joined
 int vc_comm_ranks(const VcComm* c);

@@ -41,6 +41,7 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
     cfg_degree = int(cfg_degree)
     world = degree * cfg_degree
     if world > 1:
+        ensure_ipc_env()
         if not dist.is_initialized():
             # host-side gloo for rendezvous / object broadcast (the ncclUniqueIds of the engine's communicators), torch's
             # "nccl" (= RCCL) registered for device tensors; the engine's exchanges never go through torch
@@ -55,6 +56,14 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
         torch.cuda.set_device(local)
         return torch.device("cuda", local)
     return torch.device("cpu")
+
+
+def ensure_ipc_env():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 before the first HIP call of a multi-process GPU job.  The hosts of this pool support only
+    dmabuf IPC: with the legacy mode RCCL's intra-node transport (and any CUDA-tensor sharing across processes) fails with
+    `hipIpcGetMemHandle: invalid argument` (the environment notes of this build; the variable is exported on the image already,
+    this keeps it for launchers that scrub the environment).  A value the user has set is left alone."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def make_groups(sp_degree: int, cfg_degree: int = 1):
@@ -111,6 +120,15 @@ class BatchParallel:
         out = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x, group=self.group)
         return out
+
+    def observed_ranks(self, device) -> dict:
+        """Count the ranks of this group by running a collective: every rank contributes 1 to an all-reduce on the group's
+        DEVICE backend when it has one ("nccl" = RCCL; the sum is read back), else on the host backend.  What the transport
+        saw, not what the launcher computed."""
+        on_device = torch.device(device).type == "cuda" and not dist.get_backend(self.group) == "gloo"
+        one = torch.ones(1, dtype=torch.float32, device=device if on_device else "cpu")
+        dist.all_reduce(one, group=self.group)
+        return {"ranks": int(round(float(one.item()))), "backend": "nccl" if on_device else "gloo"}
 
     def broadcast(self, x: torch.Tensor, src: int) -> torch.Tensor:
         """x from group rank `src` to everyone (in place on the other ranks)."""
@@ -231,6 +249,10 @@ def _group_has_rccl(group) -> bool:
         return dist.get_backend(group) == "nccl"
 
 
+class SequenceParallelStall(RuntimeError):
+    """The blocking rendezvous of the engine's RCCL communicators did not return within its deadline."""
+
+
 class SequenceParallel:
     """Wires the engine's Ulysses exchange to a transport (include/vcengine.h):
 
@@ -268,49 +290,95 @@ class SequenceParallel:
         self.c_all_to_all = _lib.ALL_TO_ALL_FN(self._a2a)
         self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
 
+    def _agree(self, failed: bool) -> bool:
+        """True when ANY rank of the group reports a failure (one host-side all-reduce; identity at world 1)."""
+        if self.world_size <= 1:
+            return bool(failed)
+        host_side = "gloo" in str(dist.get_backend_config(self.group))          # keep torch's own RCCL communicator unborn
+        flag = torch.tensor([1 if failed else 0], device="cpu" if host_side else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(flag.item())
+
     def attach(self, lib, handle):
         """vc_sp_init / vc_sp_init_rccl on one engine handle (called by the model when the engine is (re)configured).
-        If the engine cannot bring up its own communicators on ANY rank (the ranks agree through the torch group), every rank
-        switches to the torch transport -- still RCCL, through torch.distributed -- and says so on stderr; `transport` tells."""
+
+        The ranks AGREE before every step that can fail on one side only, so that no rank is ever alone inside a collective:
+          1. every rank binds librccl (vc_rccl_available) and rank 0 also creates the two ncclUniqueIds -> all-reduce of a
+             failure flag.  Any failure: every rank takes the torch transport (still RCCL, through torch.distributed's "nccl"
+             groups) or, on a group without an RCCL backend, every rank raises -- together.
+          2. the ids are broadcast and every rank calls vc_sp_init_rccl (ncclCommInitRank: a blocking rendezvous).  It runs on
+             a helper thread with a deadline (VC_SP_INIT_TIMEOUT seconds, default 120): a rank whose rendezvous does not
+             return raises SequenceParallelStall -- the call cannot be cancelled, so the process must end; bench.py's
+             supervisor then starts a FRESH set of ranks with VC_SP_TRANSPORT=torch (never a re-exec of a process that has
+             touched the GPU).
+          3. a second all-reduce of a failure flag (ncclCommInitRank returned an error somewhere): the same fallback."""
+        self.error = None
         if self.transport == "rccl":
+            n = _lib.VC_RCCL_UNIQUE_ID_BYTES
+            ids = C.create_string_buffer(2 * n)
             err = None
-            try:
-                self._attach_rccl(lib, handle)
-            except Exception as e:                      # library missing, bootstrap refused, ...
+            try:                                                        # step 1: nothing here blocks or involves a peer
+                _lib.check(lib.vc_rccl_available())
+                if self.rank == 0:
+                    for i in range(2):
+                        _lib.check(lib.vc_rccl_unique_id(C.byref(ids, i * n), n))
+            except Exception as e:                                      # library missing, symbol missing, wrong VC_RCCL_LIB ...
                 err = e
-            failed = err is not None
-            if self.world_size > 1:
-                host_side = "gloo" in str(dist.get_backend_config(self.group))
-                flag = torch.tensor([1 if failed else 0], device="cpu" if host_side else "cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                failed = bool(flag.item())
+            failed = self._agree(err is not None)
+            if not failed:
+                try:                                                    # step 2
+                    if self.world_size > 1:
+                        box = [ids.raw if self.rank == 0 else None]
+                        host_side = "gloo" in str(dist.get_backend_config(self.group))
+                        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0), group=self.group,
+                                                   device=torch.device("cpu") if host_side else None)
+                        ids = C.create_string_buffer(box[0], 2 * n)
+                    flags = _lib.VC_SP_FORCE_EXCHANGE if self.force_exchange else 0
+                    self._init_rccl_with_deadline(lib, handle, ids, flags)
+                except SequenceParallelStall:
+                    raise
+                except Exception as e:
+                    err = e
+                failed = self._agree(err is not None)                   # step 3
             if not failed:
                 return
             if self.world_size == 1 or not _group_has_rccl(self.group):
                 raise err if err is not None else RuntimeError("engine-owned RCCL transport failed on another rank")
             import sys
-            print(f"[versecrafter_amd] rank {self.rank}: engine-owned RCCL communicators unavailable ({err}); "
-                  "falling back to torch.distributed's RCCL process groups", file=sys.stderr)
+            print(f"[versecrafter_amd] rank {self.rank}: engine-owned RCCL communicators unavailable "
+                  f"({err if err is not None else 'failure on another rank'}); falling back to torch.distributed's RCCL "
+                  "process groups", file=sys.stderr)
             self.transport = "torch"
             if len(self._lane_groups) == 1:
                 ranks = [dist.get_global_rank(self.group, i) for i in range(self.world_size)]
                 self._lane_groups.append(dist.new_group(ranks=ranks, backend="nccl"))
         _lib.check(lib.vc_sp_init(handle, self.world_size, self.rank, self.c_all_to_all, self.c_all_gather, None), handle)
 
-    def _attach_rccl(self, lib, handle):
-        n = _lib.VC_RCCL_UNIQUE_ID_BYTES
-        ids = C.create_string_buffer(2 * n)
-        if self.rank == 0:
-            for i in range(2):
-                _lib.check(lib.vc_rccl_unique_id(C.byref(ids, i * n), n))
-        if self.world_size > 1:
-            box = [ids.raw if self.rank == 0 else None]
-            host_side = "gloo" in str(dist.get_backend_config(self.group))          # keep torch's own RCCL communicator unborn
-            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0), group=self.group,
-                                       device=torch.device("cpu") if host_side else None)
-            ids = C.create_string_buffer(box[0], 2 * n)
-        flags = _lib.VC_SP_FORCE_EXCHANGE if self.force_exchange else 0
-        _lib.check(lib.vc_sp_init_rccl(handle, self.world_size, self.rank, ids, 2, flags), handle)
+    def _init_rccl_with_deadline(self, lib, handle, ids, flags):
+        """vc_sp_init_rccl on a helper thread; SequenceParallelStall when it has not returned within the deadline."""
+        import threading
+        limit = float(os.environ.get("VC_SP_INIT_TIMEOUT", "120"))
+        box = {}
+
+        def run():
+            try:
+                box["rc"] = lib.vc_sp_init_rccl(handle, self.world_size, self.rank, ids, 2, flags)
+            except BaseException as e:          # noqa: BLE001 -- handed to the caller's thread
+                box["exc"] = e
+
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        th = threading.Thread(target=lambda: (torch.cuda.set_device(dev) if dev is not None else None, run()), daemon=True,
+                              name="vc_sp_init_rccl")
+        th.start()
+        th.join(limit if limit > 0 else None)
+        if th.is_alive():
+            raise SequenceParallelStall(
+                f"rank {self.rank}: ncclCommInitRank of the engine's communicators has not returned after {limit:.0f} s "
+                f"(world {self.world_size}).  The call cannot be cancelled: end this process and start fresh ranks with "
+                "VC_SP_TRANSPORT=torch (torch.distributed's own RCCL groups) or VC_SP_A2A=p2p; bench.py does that by itself.")
+        if "exc" in box:
+            raise box["exc"]
+        _lib.check(box["rc"], handle)
 
     def comm_ranks(self, lib, handle) -> int:
         """World size the engine's RCCL communicator reports (ncclCommCount); 0 on the callback transport."""

@@ -114,6 +114,14 @@ class _ParamTree(nn.Module):
             self._modules[head]._insert(rest, param)
 
 
+class _NoExchange:
+    """Sequence-parallel state of one rank on its own: vc_sp_init(world = 1) (drops the engine's communicators)."""
+    world_size, rank, transport, error = 1, 0, "none", None
+
+    def attach(self, lib, handle):
+        _lib.check(lib.vc_sp_init(handle, 1, 0, None, None, None), handle)
+
+
 def _ident(t: torch.Tensor):
     """Identity + version of a tensor: equal keys mean the same storage that has not been written since (no device work)."""
     return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, t.device)
@@ -332,13 +340,38 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         if batch_group is not None:
             self._bp = batch_group if hasattr(batch_group, "world_size") else vdist.BatchParallel(batch_group)   # a raw process group has gather() too
         if self._bp is not None and sp_group is None and vdist.get_sp_group() is None:
-            return                              # one rank per sample: no sequence exchange at all
+            # one rank per sample: no sequence exchange at all (an engine that was exchanging before goes back to one rank)
+            if self._sp is not None:
+                self._sp = _NoExchange()
+                self.sp_world_size, self.sp_world_rank, self.all_gather = 1, 0, None
+                self._sp_dirty = True
+            return
         custom = hasattr(sp_group, "c_all_to_all") or hasattr(sp_group, "attach")
         self._sp = sp_group if custom else vdist.SequenceParallel(sp_group)
         self.sp_world_size = self._sp.world_size
         self.sp_world_rank = self._sp.rank
         self.all_gather = getattr(self._sp, "all_gather_dim1", None)
         self._sp_dirty = True
+
+    def attach_communicators(self):
+        """Bring the sequence-parallel transport up NOW (otherwise it happens inside the first forward): the blocking
+        rendezvous of a multi-rank start is then over -- or has failed loudly -- before any weight is initialised.  Returns
+        the transport's name ("rccl", "torch" or "none")."""
+        lib, h = _lib.load(), self._engine_handle()
+        self._attach_sp(lib, h)
+        return getattr(self._sp, "transport", "none") if self._sp is not None else "none"
+
+    def _attach_sp(self, lib, h) -> bool:
+        if not self._sp_dirty:
+            return False
+        sp = self._sp
+        if hasattr(sp, "attach"):
+            sp.attach(lib, h)            # RCCL communicators inside the engine, or the callback transport
+        else:                            # tests inject a bare callback object
+            _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
+        self._sp_dirty = False
+        self._video_key = self._video_ident = None
+        return True
 
     # ------------------------------------------------------------------ engine plumbing
     def _engine_handle(self):
@@ -392,13 +425,7 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             _lib.check(lib.vc_set_rope_table(h, C.cast(tab.data_ptr(), C.POINTER(C.c_double)), tab.shape[0],
                                              tab.shape[1]), h)
             self._rope_dirty = False
-        if self._sp_dirty:
-            sp = self._sp
-            if hasattr(sp, "attach"):
-                sp.attach(lib, h)            # RCCL communicators inside the engine, or the callback transport
-            else:                            # tests inject a bare callback object
-                _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
-            self._sp_dirty = False
+        if self._attach_sp(lib, h):
             changed = True
         if changed:
             self._video_key = self._video_ident = None

@@ -47,8 +47,9 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, rows_per_bat
     return out
 
 
-def attention(q, k, v, k_len=0, scale=None, out=None):
-    """q [B,Lq,H,128], k/v [B,Lk,H,128] (any strides with a contiguous last dim) -> [B,Lq,H,128]."""
+def attention(q, k, v, k_len=0, scale=None, out=None, variant=0):
+    """q [B,Lq,H,128], k/v [B,Lk,H,128] (any strides with a contiguous last dim) -> [B,Lq,H,128].
+    variant (tests / A-B tools): MFMA shape of the pipelined kernel, 32 or 16; 0 = the library's default."""
     lib = _lib.load()
     _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
     B, Lq, H, D = q.shape
@@ -59,8 +60,12 @@ def attention(q, k, v, k_len=0, scale=None, out=None):
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     st = lambda t: _lib.i64x3(t.stride(0), t.stride(1), t.stride(2))
-    rc = lib.vc_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out),
-                             int(k_len), float(scale), _stream())
+    if variant:
+        rc = lib.vc_op_attention_variant(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out),
+                                         int(k_len), float(scale), int(variant), _stream())
+    else:
+        rc = lib.vc_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out),
+                                 int(k_len), float(scale), _stream())
     _lib.check(rc)
     return out
 
