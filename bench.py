@@ -422,7 +422,7 @@ def run_rank(args):
         if world % args.cfg_degree:
             raise SystemExit(f"--cfg-degree {args.cfg_degree} does not divide --gpus {world}")
         layouts = [(args.cfg_degree, world // args.cfg_degree)]
-    elif world == 2 and not rehearsal:
+    elif world == 2:
         layouts = [(1, 2), (2, 1)]
     else:
         layouts = [(1, world)]
@@ -453,9 +453,9 @@ def run_rank(args):
         configure(lay)
         obs = {}
         if use_dist:
-            transport = model.attach_communicators()
+            model.attach_communicators()
             if lay[1] > 1 or world == 1:
-                obs["sp"] = model._sp.probe(dev) if hasattr(model._sp, "probe") else {"ranks": 0, "transport": transport}
+                obs["sp"] = model.probe_exchange(dev)
             if lay[0] > 1:
                 obs["cfg"] = model._bp.observed_ranks(dev)
         observed[lay] = obs
@@ -520,12 +520,9 @@ def run_rank(args):
         # what the transports of this layout say about their size NOW, after they carried the timed steps
         obs = dict(observed.get(lay, {}))
         if use_dist and (lay[1] > 1 or world == 1) and model._sp is not None:
-            obs["sp"] = dict(obs.get("sp", {}), ranks=model._sp.observed_ranks(_lib_handle(model), dev))
+            obs["sp"] = dict(obs.get("sp", {}), ranks=model.sp_observed_ranks(dev))
         return {"layout": lay, "elapsed": elapsed, "prof": prof, "finite": finite, "observed": obs,
                 "transport": getattr(model._sp, "transport", "none") if lay[1] > 1 or (world == 1 and use_dist) else "none"}
-
-    def _lib_handle(m):
-        return m._engine_handle()
 
     results = [timed(lay) for lay in layouts]
 

@@ -110,6 +110,9 @@ int vc_rccl_unique_id(void* out, int nbytes);
 int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, int n_ids, uint32_t flags);
 int vc_sp_comm_ranks(const vc_engine* h);
 int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+/* nslab all-to-alls on consecutive [world][bytes_per_peer] slabs as the step path issues them (ONE RCCL group on the engine-owned
+ * transport, one callback per slab otherwise) */
+int vc_sp_all_to_all_n(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, int nslab, void* stream);
 int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream);
 /* What-if timing of ONE rank of a `world`-way run on a single GPU (tools/sim_sp_rank.py): every exchange is a local copy
  * followed by one idle wave that holds the chain's stream for (bytes leaving the rank) / egress_gbps -- the rank's compute
@@ -265,6 +268,42 @@ const char* vc_vae_last_error(const vc_vae* h);
 int64_t vc_vae_workspace_bytes(const vc_vae* h);
 int vc_vae_release_workspace(vc_vae* h);
 void vc_vae_destroy(vc_vae* h);
+
+/* ---- 4D control-map renderer (second half): the per-pixel stages of inference/rendering_4D_control_maps.py.
+ * Device pointers; images are [H][W] (depth float32, masks uint8 0/1) and [H][W][3] uint8; a call may cover a whole batch of frames
+ * (npix = B H W).  Python mirror with the reference's function names: versecrafter_amd/rendering/control_maps.py.
+ *   vc_op_render_composite     take_fg = fg_mask & (bg_depth <= 0 | (fg_depth > 0 & fg_depth < bg_depth - 1e-6)); out_rgb / out_depth take
+ *                              the foreground there (composite_by_depth_batch :398-411); out_mask (optional, needs bg_mask) = 255 x
+ *                              (take_fg ? 1 : !bg_mask) on three channels (merge_bg_and_fg_mask :736-763).  Any output may be NULL.
+ *   vc_op_render_depth_gray    disparity 1/d (0 where d <= 0), (disp - min_disp) / denom when normalize, clamp, x 255 truncated (:520-537);
+ *                              min_disp and denom are computed by the host exactly as the reference computes them.
+ *   vc_op_render_gauss_density sum over n projected Gaussians of coeff exp(-mahalanobis / 2) at pixel (u, v) = (column, row) (:801-883).
+ *                              records: n x 12 floats {mean_u, mean_v, inv00, inv01, inv10, inv11, coeff, valid, r, g, b, 0}.
+ *   vc_op_render_gauss_frame   the same records in compositing order (far to near): each density map is divided by its maximum + 1e-8,
+ *                              alpha = (d - threshold) / span above the threshold, "over" compositing of colour and alpha (:660-693);
+ *                              scratch_max: n x 4 bytes.  out_rgb uint8 [H][W][3], out_alpha float32 [H][W].
+ *   vc_op_render_blend         C = fg/255 alpha + bg/255 (1 - alpha) -> uint8 (:719-732); masked != 0: fg/255 alpha 255 (:1322-1326).
+ * PARITY UNPINNED (PyTorch3D is not in the reference tree; restated from its published algorithms, specification = oracle/render_oracle.py):
+ *   vc_op_render_points        PointsRasterizer(radius, points_per_pixel K) + AlphaCompositor(background) of :243-338 for ONE camera:
+ *                              points [n][3] float32 (world), colors [n][3] uint8, w2c row-major [4][4] (OpenCV world-to-camera,
+ *                              :1001-1009), K3 row-major [3][3] pixel intrinsics (HOST pointers) -> rgb uint8, depth float32, mask uint8.
+ *   vc_op_render_mesh          MeshRasterizer(blur 0, 1 face per pixel) + HardPhongShader(point light) of :150-241 for ONE camera:
+ *                              verts [nv][3] float32 (world), vert_colors [nv][3] float32 in [0, 1], faces [nf][3] int32.               */
+const char* vc_render_last_error(void);
+int vc_op_render_composite(const void* bg_rgb, const void* bg_depth, const void* fg_rgb, const void* fg_depth, const void* fg_mask,
+                           const void* bg_mask, void* out_rgb, void* out_depth, void* out_mask, int64_t npix, void* stream);
+int vc_op_render_depth_gray(const void* depth, void* out_rgb, int64_t npix, int normalize, float min_disp, float denom, void* stream);
+int vc_op_render_gauss_density(const void* records, int n, void* out, int W, int H, void* stream);
+int vc_op_render_gauss_frame(const void* records, int n, void* scratch_max, float threshold, float span, void* out_rgb, void* out_alpha, int W,
+                             int H, void* stream);
+int vc_op_render_blend(const void* fg_rgb, const void* alpha, const void* bg_rgb, void* out_rgb, int64_t npix, int masked, void* stream);
+int64_t vc_op_render_points_scratch_bytes(int64_t npoints, int W, int H, int K);
+int vc_op_render_points(const void* points, const void* colors, int64_t npoints, const float* w2c, const float* K3, int W, int H, float radius,
+                        int K, float background, void* scratch, void* out_rgb, void* out_depth, void* out_mask, void* stream);
+int64_t vc_op_render_mesh_scratch_bytes(int nverts, int W, int H);
+int vc_op_render_mesh(const void* verts, const void* vert_colors, int nverts, const void* faces, int nfaces, const float* w2c, const float* K3,
+                      const float* light_xyz, const float* eye_xyz, int W, int H, int background_u8, void* scratch, void* out_rgb,
+                      void* out_depth, void* out_mask, void* stream);
 
 #ifdef __cplusplus
 }

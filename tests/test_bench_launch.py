@@ -31,16 +31,90 @@ def test_self_launch_propagates_rank_failure():
 
 
 def test_launcher_parent_does_not_import_torch():
-    """The parent must start the ranks before anything can touch the GPU: bench.py's module level and launch_ranks import
-    neither torch nor the engine."""
+    """The supervisor must start the ranks before anything can touch the GPU: bench.py's module level imports neither torch nor
+    the engine, launch_ranks imports nothing of either (its torchrun-mode board imports torch.distributed's STORE only -- host
+    sockets, no device), and a multi-rank run_rank happens only in a child (VC_BENCH_CHILD)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     for line in src.splitlines():                               # module level
         assert not line.startswith(("import torch", "from torch", "from versecrafter_amd", "import versecrafter_amd")), line
-    body = src[src.index("def launch_ranks("):src.index("def main(")]
+    body = src[src.index("def launch_ranks("):src.index("def _mark(")]
     stmts = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("import ", "from "))]
     assert stmts and not any("torch" in ln or "versecrafter_amd" in ln for ln in stmts), stmts
+    board = src[src.index("class _StoreBoard"):src.index("def _tail(")]
+    stmts = [ln.strip() for ln in board.splitlines() if ln.strip().startswith(("import ", "from "))]
+    assert all(ln.startswith(("from datetime", "from torch.distributed import PrefixStore, rendezvous")) for ln in stmts), stmts
     main = src[src.index("def main("):src.index("def run_rank(")]
-    assert main.index("launch_ranks(args)") < main.index("run_rank(args)")
+    assert main.index("launch_ranks(args)") < main.index("run_rank(args)") and "VC_BENCH_CHILD" in main
+
+
+FAKE = os.path.join(ROOT, "tests", "_fake_bench_rank.py")
+FAST = {"VC_BENCH_UP_TIMEOUT": "2", "VC_BENCH_START_TIMEOUT": "60", "VC_BENCH_KILL_GRACE": "1", "VC_BENCH_TEST_CHILD": FAKE}
+
+
+def _err_files(tmp_path, n):
+    return [tmp_path / f"bench_n{n}.rank{r}.err" for r in range(n)]
+
+
+def test_supervisor_stall_starts_a_fresh_set_on_the_torch_transport(tmp_path):
+    """First contact of a multi-rank run must produce a line, not a timeout: children that block instead of bringing their
+    communicators up are killed after the bring-up deadline and a FRESH set runs with VC_SP_TRANSPORT=torch."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "3"], env=dict(FAST, FAKE_MODE="stall_first", VC_BENCH_LOG_DIR=str(tmp_path)), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 60
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 3 and out["transport"] == "torch"
+    assert "stall" in r.stderr and "fresh set of ranks with VC_SP_TRANSPORT=torch" in r.stderr
+    for f in _err_files(tmp_path, 3):                           # one stderr file per rank, both attempts in it
+        txt = f.read_text()
+        assert "==== attempt 0" in txt and "==== attempt 1" in txt and "blocking in the rendezvous" in txt
+
+
+def test_supervisor_gives_up_with_per_rank_tails_when_the_fallback_stalls_too(tmp_path):
+    r = _run(["--gpus", "2"], env=dict(FAST, FAKE_MODE="stall_always", VC_BENCH_LOG_DIR=str(tmp_path)), timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert r.stderr.count("stall") >= 2
+    assert "---- rank 0 stderr tail" in r.stderr and "---- rank 1 stderr tail" in r.stderr
+    assert "blocking in the rendezvous" in r.stderr
+
+
+def test_supervisor_budget_bounds_the_whole_run(tmp_path):
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2"], env=dict(FAST, FAKE_MODE="stall_always", VC_BENCH_UP_TIMEOUT="30", VC_BENCH_BUDGET="3",
+                                       VC_BENCH_LOG_DIR=str(tmp_path)), timeout=120)
+    assert r.returncode != 0 and "over the run budget" in r.stderr
+    assert time.time() - t0 < 30
+
+
+def test_supervisor_rank_death_during_bring_up_is_a_transport_failure(tmp_path):
+    """A rank that dies between "started" and "up" (ncclCommInitRank returned an error on one side) leaves its peers blocked:
+    they are killed after the grace period and the fresh set takes the torch transport."""
+    r = _run(["--gpus", "2"], env=dict(FAST, FAKE_MODE="die_in_bringup", VC_BENCH_LOG_DIR=str(tmp_path)), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip())["transport"] == "torch"
+    assert "transport: rank 1 exited with code 3" in r.stderr
+
+
+def test_supervisor_under_torchrun_one_supervisor_per_rank(tmp_path):
+    """The driver's N > 1 command line: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N.  Every torchrun
+    worker supervises its own rank's child; they agree through torchrun's store (stall -> everybody restarts on torch); the
+    children rendezvous on a port of their own; rank 0's supervisor prints the one line."""
+    e = dict(os.environ, **FAST, FAKE_MODE="stall_first", VC_BENCH_LOG_DIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["transport"] == "torch" and int(out["master_port"]) != port
+    assert all(f.exists() for f in _err_files(tmp_path, 2))
 
 
 @pytest.mark.gpu
@@ -61,15 +135,28 @@ def test_self_launch_two_ranks_rehearsal_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_self_launch_two_ranks_default_is_one_cfg_sample_per_rank():
-    """--gpus 2 without --cfg-degree: the CFG pair is split across the two ranks (no sequence exchange), outputs gathered."""
+def test_self_launch_two_ranks_default_measures_both_layouts():
+    """--gpus 2 without --cfg-degree: BOTH ways of using two ranks are timed in the one run -- Ulysses over the two ranks
+    (north_star's curve) and one CFG sample per rank (no sequence exchange, outputs gathered); the faster is the headline, the
+    other sits under "alt" with its own value; --cfg-degree 2 pins the split."""
     r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "cfg2 x ulysses-sp1"
-    assert out["outputs_finite"] is True and out["value"] > 0 and "REHEARSAL" in out["transport"]
+    assert out["n_gpus"] == 2 and len(out["alt"]) == 1
+    both = {out["config"]["parallelism"]: out, out["alt"][0]["parallelism"]: out["alt"][0]}
+    assert set(both) == {"ulysses-sp2", "cfg2 x ulysses-sp1"}
+    assert out["value"] >= out["alt"][0]["value"] > 0
+    assert out["outputs_finite"] is True and out["alt"][0]["outputs_finite"] is True and "REHEARSAL" in out["transport"]
+    cfg_line = both["cfg2 x ulysses-sp1"]
+    assert (cfg_line.get("cfg") or cfg_line["config"]["cfg"]) == "one sample per rank"
+    assert cfg_line["rccl_observed"]["cfg"] == {"ranks": 2, "backend": "gloo"}       # counted by an all-reduce, not computed
+    r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
+              "--cfg-degree", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["config"]["parallelism"] == "cfg2 x ulysses-sp1" and "alt" not in out
 
 
 @pytest.mark.gpu

@@ -119,6 +119,43 @@ def test_teacache_with_cfg_skip_crosses_the_batch_switch(fwd):
             assert torch.equal(ya[0], ya[1]) and torch.equal(ya[1], yb[1]), i
 
 
+def test_graph_replay_of_a_skipped_step_follows_the_residual_slot_across_the_batch_switch(fwd, monkeypatch):
+    """Advisor finding (round 2): a captured USE_RESIDUAL graph bakes in the slot's read offset (resid_B - B) rows
+    (previous_residual[-B:], VC.py:396).  Store at B = 2, cfg_skip drops to B = 1, two skipped steps capture a graph that
+    reads the LAST sample of the pair; a calc step then stores at B = 1 (no reallocation, so nothing dropped the graph) and
+    the next skipped step must read sample 0 of the new residual, not the stale half of the old one.  Eager recomputes the
+    pointer; the graph path must equal it bit for bit on every step."""
+    L = int(fwd["A.seq_len"])
+    xs = [fwd["A.x"], fwd["C.x2"], fwd["A.x"] * 0.5, fwd["C.x2"] * 0.75, fwd["A.x"] * -0.3, fwd["C.x2"] * 0.4]
+    ts = [fwd["C.t1"], fwd["C.t2"], fwd["C.t2"] - 40.0, fwd["C.t2"] - 80.0, fwd["C.t2"] - 120.0, fwd["C.t2"] - 160.0]
+    calc = [True, False, False, True, False, False]          # B = 2 store | B = 1: skip, skip (capture), calc + store, skip, skip
+    monkeypatch.setenv("VC_GRAPH", "0")
+    eager = _fresh_model()
+    monkeypatch.setenv("VC_GRAPH", "1")
+    graph = _fresh_model()
+    outs = {}
+    for name, m in (("eager", eager), ("graph", graph)):
+        m.enable_teacache([1.0, 0.0], num_steps=len(calc), rel_l1_thresh=1e9, num_skip_start_steps=1, offload=False)
+        m.enable_cfg_skip(5.0 / 6.0, len(calc))              # from step 1 on: conditional half only
+        it = iter(calc)
+        tc = m.teacache
+
+        def gate(e0, tc=tc, it=it):
+            tc.previous_modulated_input = e0
+            tc.should_calc = next(it)
+            return tc.should_calc
+        tc.gate = gate
+        ys = []
+        for i in range(len(calc)):
+            m.current_steps = i
+            ys.append(run(m, fwd, L, x=xs[i], t=ts[i]))
+            assert m.should_calc == calc[i]
+        outs[name] = ys
+    for i, (a, b) in enumerate(zip(outs["graph"], outs["eager"])):
+        assert torch.equal(a, b), f"step {i}: graph replay differs from the eager engine"
+    assert not torch.equal(outs["eager"][4], outs["eager"][2])
+
+
 def test_teacache_keeps_separate_cond_and_uncond_residuals(fwd):
     """cond_flag=False forwards (VC.py:391-394, 408-411) store and re-use previous_residual_uncond, never the conditional
     residual; their gate decision is the conditional call's (WT.py:244-245)."""

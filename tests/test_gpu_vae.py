@@ -96,6 +96,35 @@ def test_production_width_small_clip_vs_oracle():
     assert e1 < 3e-2 and e2 < 3e-2
 
 
+def test_config4_frame_size_encode_decode_properties():
+    """BASELINE config 4's clip, 81 frames of 720 x 1280, through the production-width VAE (random weights; the CPU oracle is
+    out of reach at this size -- ~1.5 PFLOP): shapes, finiteness, the decoder's clamp, and a size-independent property of the
+    architecture -- the encoder is CAUSAL in time, so the first 41 frames alone must give the first 11 latent frames of the
+    whole clip bit for bit (every output row is the same sequence of operations whatever the clip length).  The workspace is
+    reported: the whole-sequence form needs five buffers of the largest activation (the 2x-upsampled 192-channel tensor)."""
+    cfg, Wf, m = make(dict(dim=96, z_dim=16), 11)
+    g = torch.Generator().manual_seed(4)
+    F, H, W = 81, 720, 1280
+    x = (torch.rand(1, 3, F, H, W, generator=g) * 2 - 1).bfloat16().cuda()
+    lat = m.encode(x)[0].mode()
+    torch.cuda.synchronize()
+    ws_enc = m.workspace_bytes()
+    assert lat.shape == (1, 16, 21, H // 8, W // 8) and torch.isfinite(lat.float()).all()
+    head = m.encode(x[:, :, :41].contiguous())[0].mode()
+    torch.cuda.synchronize()
+    assert head.shape == (1, 16, 11, H // 8, W // 8) and torch.equal(head, lat[:, :, :11])
+    del x, head
+    z = torch.randn(1, 16, 21, H // 8, W // 8, generator=g).bfloat16().cuda()
+    vid = m.decode(z).sample
+    torch.cuda.synchronize()
+    ws_dec = m.workspace_bytes()
+    assert vid.shape == (1, 3, F, H, W) and torch.isfinite(vid.float()).all() and vid.float().abs().max() <= 1.0
+    assert vid.float().std() > 0
+    print(f"config-4 clip: VAE workspace {ws_enc / 2**30:.1f} GiB after encode, {ws_dec / 2**30:.1f} GiB after decode")
+    assert ws_dec < 200 * 2**30
+    m.release_workspace()
+
+
 def test_cli_full_flow_with_vae_and_frame_dumps(tmp_path):
     """inference/versecrafter_inference.py as the reference runs it (CLI.py:187-465), on tiny random models: control maps and
     mask read from frame dumps next to the (absent) .mp4 names, first frame from a .png, VAE-encoded on the engine, denoised,

@@ -1,0 +1,146 @@
+"""CPU: the renderer's oracle (oracle/render_oracle.py) and the product's HOST logic (versecrafter_amd/rendering/control_maps.py: file
+readers, colours, camera arithmetic, the 3x3 Gaussian projection records, the icosphere) against fixtures recorded from the reference's
+own inference/rendering_4D_control_maps.py (tests/golden/make_golden_render.py -> render_small.safetensors)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import render_oracle as RO
+from versecrafter_amd.rendering import control_maps as CM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return load_file(os.path.join(ROOT, "tests", "golden", "render_small.safetensors"))
+
+
+def test_oracle_depth_compositing_bit_exact(fx):
+    rgb, depth = RO.composite_by_depth(fx["comp.bg_rgb"], fx["comp.bg_depth"], fx["comp.fg_rgb"], fx["comp.fg_depth"], fx["comp.fg_mask"].bool())
+    assert torch.equal(rgb, fx["comp.out_rgb"]) and torch.equal(depth, fx["comp.out_depth"])
+    mm = RO.merge_mask(fx["comp.bg_depth"], fx["comp.fg_depth"], fx["comp.bg_mask"].bool(), fx["comp.fg_mask"].bool())
+    assert torch.equal(mm, fx["comp.merged_mask"])
+
+
+def test_oracle_depth_visualisation_bit_exact(fx):
+    frames = list(fx["comp.bg_depth"])
+    lo, hi = RO.global_depth_range([frames, list(fx["comp.fg_depth"]), list(fx["comp.out_depth"])])
+    assert [lo, hi] == fx["depth.range"].tolist()
+    assert torch.equal(torch.stack(RO.depth_to_gray(frames, lo, hi)), fx["depth.gray_global"])
+    assert torch.equal(torch.stack(RO.depth_to_gray(frames)), fx["depth.gray_auto"])
+    assert torch.equal(torch.stack(RO.depth_to_gray([torch.zeros(20, 28)])), fx["depth.gray_empty"])
+    assert list(RO.global_depth_range([[torch.zeros(4, 4)]])) == fx["depth.range_empty"].tolist()
+
+
+def _frames(fx):
+    out = []
+    for f in range(3):
+        ids = [str(int(i)) for i in fx[f"gauss.f{f}.ids"]]
+        out.append({i: (fx[f"gauss.f{f}.means"][k], fx[f"gauss.f{f}.covs"][k]) for k, i in enumerate(ids)})
+    col = {str(int(k)): int(v) for k, v in fx["gauss.color_idx"]}
+    return out, col
+
+
+def test_oracle_gaussian_projection_bit_exact(fx):
+    K, E = fx["gauss.K"], fx["gauss.ext"]
+    d = RO.density_map(fx["gauss.means0"], fx["gauss.covs0"], K, E[0][:3, :3], E[0][:3, 3:4], (48, 36))
+    assert torch.equal(d, fx["gauss.density_sum"])
+    d1 = RO.density_map(fx["gauss.means0"][1:2], fx["gauss.covs0"][1:2], K, E[0][:3, :3], E[0][:3, 3:4], (48, 36))
+    assert torch.equal(d1, fx["gauss.density_1"])
+    params, col = _frames(fx)
+    for thr in (0.05, 0.003):
+        rgbs, alphas = RO.project_gaussians(params, col, [K.numpy()] * 3, list(E.numpy()), (48, 36), threshold=thr)
+        assert torch.equal(torch.stack(rgbs), fx[f"gauss.rgb_t{thr}"]) and torch.equal(torch.stack(alphas), fx[f"gauss.alpha_t{thr}"])
+    blend = torch.stack([RO.blend_with_bg(r, a, b) for r, a, b in zip(rgbs, alphas, fx["gauss.bg"])])
+    assert torch.equal(blend, fx["gauss.blend"])
+
+
+def test_palette_and_colour_helpers_match_the_reference(fx):
+    for i in range(22):
+        assert torch.equal(RO.object_color(i, {i: i}, True), fx["color.float"][i])
+        assert torch.equal(RO.object_color(i, {i: i}), fx["color.u8"][i])
+        assert torch.equal(CM.get_object_color(i, {i: i}, "cpu", return_float=True), fx["color.float"][i])
+        assert torch.equal(CM.get_object_color(i, {i: i}, "cpu"), fx["color.u8"][i])
+    assert torch.equal(CM.get_object_color("x", {}, "cpu"), fx["color.u8"][0])          # unknown id -> colour 0
+    assert np.array_equal(CM.COORD_TRANSFORM_CV2BLENDER, fx["coord.cv2blender"].numpy())
+
+
+def test_camera_trajectory_reader_and_camera_arithmetic(fx, tmp_path):
+    """custom_camera_trajectory.npz (`extrinsics` float [F,4,4], Blender camera-to-world) -> OpenCV world-to-camera."""
+    p = tmp_path / "custom_camera_trajectory.npz"
+    np.savez(p, extrinsics=fx["cam.c2w_blender"].numpy().astype(np.float64))
+    w2c = CM.load_camera_trajectory(str(p), device="cpu")
+    assert torch.equal(w2c, fx["cam.w2c_opencv"]) and torch.equal(RO.camera_trajectory(fx["cam.c2w_blender"].numpy()), fx["cam.w2c_opencv"])
+    Ks = fx["gauss.K"].repeat(5, 1, 1)
+    for fn in (CM.build_pytorch3d_camera_parameters, RO.p3d_cameras):
+        R, T, focal, pp = fn(Ks, w2c.clone())
+        assert torch.equal(R, fx["cam.p3d_R"]) and torch.equal(T, fx["cam.p3d_T"])
+        assert torch.equal(focal, fx["cam.p3d_focal"]) and torch.equal(pp, fx["cam.p3d_pp"])
+
+
+def test_ellipsoid_parameter_reader(fx, tmp_path):
+    doc = json.loads(bytes(fx["ell.json"].tolist()).decode())
+    p = tmp_path / "ell.json"
+    p.write_text(json.dumps(doc))
+    params, cidx, centers = CM.load_ellipsoid_parameters(str(p), device="cpu")
+    assert cidx == {"3": 1, "5": 4} and sorted(centers) == [0, 1] and len(params) == 2
+    for f in range(2):
+        for j, oid in enumerate((3, 5)):
+            assert torch.equal(params[f][oid][0], fx["ell.means"][f, j]) and torch.equal(params[f][oid][1], fx["ell.covs"][f, j])
+            assert torch.equal(centers[f][oid], fx["ell.means"][f, j])
+    op, oc = RO.ellipsoid_parameters(doc)
+    assert oc == cidx and torch.equal(op[1][5][1], fx["ell.covs"][1, 1])
+
+
+def test_host_gaussian_records_equal_the_oracle(fx):
+    """The 12-float record the HIP kernels consume is the reference's own 3x3 arithmetic (:828-873), statement by statement."""
+    K, E = fx["gauss.K"], fx["gauss.ext"]
+    for f in range(3):
+        R, t = E[f][:3, :3], E[f][:3, 3:4]
+        for mean, cov in zip(fx[f"gauss.f{f}.means"], fx[f"gauss.f{f}.covs"]):
+            rec, z = CM._gaussian_record(mean, cov, K, R, t)
+            ok, m2, inv, coeff = RO.gaussian_record(mean, cov, K, R, t)
+            assert z == float((R @ mean + t.squeeze())[2])
+            assert bool(rec[7]) == ok
+            if ok:
+                got = torch.tensor(rec[:7])
+                want = torch.cat([m2, inv.flatten(), coeff.reshape(1)])
+                assert torch.equal(got, want)
+
+
+def test_icosphere_is_a_closed_unit_sphere_mesh():
+    for level, (nv, nf) in {0: (12, 20), 1: (42, 80), 3: (642, 1280)}.items():
+        v, f = CM.ico_sphere(level)
+        assert v.shape == (nv, 3) and f.shape == (nf, 3) and f.dtype == torch.int32
+        assert torch.allclose(v.norm(dim=1), torch.ones(nv), atol=1e-6)
+        edges = set()
+        for a, b, c in f.tolist():
+            edges |= {(min(a, b), max(a, b)), (min(b, c), max(b, c)), (min(a, c), max(a, c))}
+        assert nv - len(edges) + nf == 2                            # Euler characteristic of a sphere
+        n = torch.linalg.cross(v[f[:, 1].long()] - v[f[:, 0].long()], v[f[:, 2].long()] - v[f[:, 0].long()])
+        assert ((n * v[f[:, 0].long()]).sum(1) > 0).all()           # consistently outward-facing
+        vo, fo = RO.ico_sphere(level)
+        assert torch.equal(v, vo) and torch.equal(f, fo)
+    m = CM.make_ellipsoid_mesh(torch.tensor([1.0, 2.0, 3.0]), torch.diag(torch.tensor([0.04, 0.09, 0.25])), scale_factor=2.5, subdivisions=2,
+                               color_rgb255=torch.tensor([10, 20, 30], dtype=torch.uint8), device="cpu")
+    ext = (m.verts - torch.tensor([1.0, 2.0, 3.0])).abs().max(dim=0).values
+    assert torch.allclose(ext, 2.5 * torch.tensor([0.2, 0.3, 0.5]), atol=2e-2)     # semi-axes = scale x sqrt(eigenvalues)
+    assert torch.allclose(m.colors[0], torch.tensor([10, 20, 30]) / 255.0)
+    both = CM.combine_meshes_for_scene([m, m])
+    assert both.verts.shape[0] == 2 * m.verts.shape[0] and int(both.faces.max()) == 2 * m.verts.shape[0] - 1
+
+
+def test_mask_dilation_matches_an_elliptical_structuring_element():
+    m = torch.zeros(31, 31, dtype=torch.bool)
+    m[15, 15] = True
+    d = CM._dilate_ellipse(m, 10)
+    ys, xs = torch.nonzero(d, as_tuple=True)
+    assert d[15, 15] and int(d.sum()) > 60 and (ys - 15).abs().max() <= 5 and (xs - 15).abs().max() <= 5
+    assert not d[10, 10] and not d[20, 20]                          # the corners of the 10 x 10 box are outside the ellipse
+    pts = CM.depth_to_points(torch.full((4, 6), 2.0), torch.tensor([[3.0, 0, 2.5], [0, 4.0, 1.5], [0, 0, 1]]))
+    assert torch.allclose(pts[1, 2], torch.tensor([(2 - 2.5) * 2 / 3, (1 - 1.5) * 2 / 4, 2.0]))

@@ -100,3 +100,53 @@ def test_layout_contract_roundtrip():
         loc = vdist.unpack_heads(recv2)                                    # [B, Lloc, N, D] of token chunk dst
         want = torch.cat([o[src][:, dst * Lloc:(dst + 1) * Lloc] for src in range(P)], dim=2)
         assert torch.equal(loc, want)
+
+
+def _attach_worker(rank, world, port, bad_ranks, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    if rank in bad_ranks:
+        os.environ["VC_RCCL_LIB"] = "/nonexistent/librccl.so.1"       # read when librccl is first bound in this process
+    import time
+    from versecrafter_amd import _lib, dist as vdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sp = vdist.SequenceParallel(dist.group.WORLD, transport="rccl")
+        t0 = time.time()
+        try:
+            sp.attach(_lib.load(), None)          # the handle is never reached: the ranks agree to fail before vc_sp_init_rccl
+            outcome = "attached:" + sp.transport
+        except Exception as e:                    # noqa: BLE001
+            outcome = type(e).__name__ + ": " + str(e)[:120]
+        # still in step with the peer: a collective on the same group completes
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        q.put((rank, outcome, time.time() - t0, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_ranks", [(0,), (1,), (0, 1)])
+def test_rccl_bring_up_failure_on_one_side_fails_on_every_rank_together(bad_ranks):
+    """Advisor finding (round 2): rank 0 failing before broadcast_object_list left the other ranks inside it.  Now every rank
+    binds librccl (and rank 0 makes the ids) FIRST, then one all-reduce of a failure flag decides for everybody.  On a gloo-only
+    group there is no RCCL fallback, so every rank raises -- within seconds, and the group is still usable afterwards."""
+    world = 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_attach_worker, args=(r, world, port, bad_ranks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outcome, dt, total in res:
+        assert not outcome.startswith("attached"), res
+        assert dt < 60 and total == 1.0, res
+        if rank in bad_ranks:
+            assert "librccl" in outcome or "nonexistent" in outcome, res
+        else:
+            assert "another rank" in outcome, res

@@ -58,6 +58,7 @@ SYMBOLS = {
     "vc_sp_init_rccl": (_I, [_P, _I, _I, _P, _I, C.c_uint32]),
     "vc_sp_comm_ranks": (_I, [_P]),
     "vc_sp_all_to_all": (_I, [_P, _I, _P, _P, _L, _P]),
+    "vc_sp_all_to_all_n": (_I, [_P, _I, _P, _P, _L, _I, _P]),
     "vc_sp_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "vc_sp_init_sim": (_I, [_P, _I, _I, C.c_double]),
     "vc_prepare_video": (_I, [_P, _P, C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _P]),
@@ -76,6 +77,17 @@ SYMBOLS = {
                                        C.POINTER(_L), _I, _I, _F, _P]),
     "vc_op_attention_padmerge": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                       C.POINTER(_L), C.POINTER(C.c_int32), _F, _P]),
+    "vc_render_last_error": (C.c_char_p, []),
+    "vc_op_render_composite": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "vc_op_render_depth_gray": (_I, [_P, _P, _L, _I, _F, _F, _P]),
+    "vc_op_render_gauss_density": (_I, [_P, _I, _P, _I, _I, _P]),
+    "vc_op_render_gauss_frame": (_I, [_P, _I, _P, _F, _F, _P, _P, _I, _I, _P]),
+    "vc_op_render_blend": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "vc_op_render_points_scratch_bytes": (_L, [_L, _I, _I, _I]),
+    "vc_op_render_points": (_I, [_P, _P, _L, C.POINTER(_F), C.POINTER(_F), _I, _I, _F, _I, _F, _P, _P, _P, _P, _P]),
+    "vc_op_render_mesh_scratch_bytes": (_L, [_I, _I, _I]),
+    "vc_op_render_mesh": (_I, [_P, _P, _I, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _I, _I, _P, _P, _P, _P,
+                               _P]),
     "vc_op_layernorm": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _L, _P]),
     "vc_op_rmsnorm_rope": (_I, [_P, _L, _I, _I, _P, _F, _P, C.POINTER(C.c_int32), _P]),
     "vc_op_qkv_front": (_I, [_P, _I, _I, _P, _P, _F, _P, C.POINTER(C.c_int32), _P, _I, _P]),

@@ -652,7 +652,7 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
             nt_max = nt_max > (kl + KT - 1) / KT ? nt_max : (kl + KT - 1) / KT;
         }
         if (nt_max <= SHORT_MAX_TILES && p.Lq >= 128) return launch_attn_short<true>(p, nt_max, stream);
-        return launch_attn_pipe<false, 4, true>(p, stream);
+        return vc_launch_attention_stream(p, stream);        // 5-8 tiles: plain double-buffered kernel (attention_stream.hip)
     }
     if (p.seg_len == 0 && p.Lk <= SHORT_MAX_TILES * KT && p.Lq >= 1024) return launch_attn_short<false>(p, (p.Lk + KT - 1) / KT, stream);
     // MFMA shape of the pipelined kernel (round 3 A/B): variant 16 / 32 force one, 0 takes VC_ATTN_DEFAULT_SHAPE

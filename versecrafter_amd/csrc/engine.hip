@@ -150,7 +150,10 @@ struct vc_engine {
     // attributes, allocates TeaCache slots), the second is captured on an engine stream against staging copies of x / t / out,
     // later ones copy the inputs in, launch the graph on the caller's stream and copy the result out.  One rank, one stream,
     // profiling off only; VC_GRAPH=0 / 1 forces it off / on (default: rows M <= 16384).
-    struct GraphEntry { uint32_t flags; float scale; int seen; hipGraph_t graph; hipGraphExec_t exec; };
+    // rkey: samples held by the TeaCache slot a USE_RESIDUAL graph re-adds (-1 otherwise).  The captured kernel reads the slot at
+    // the byte offset (resid_B - B) * Lloc * d * 2 (previous_residual[-B:], VC.py:396), and resid_B can change with no
+    // reallocation (store at B = 2, cfg_skip drops to B = 1, a later store at B = 1): it is part of the key, not of the graph.
+    struct GraphEntry { uint32_t flags; float scale; int rkey; int seen; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     int graph_mode = -1;            // -1 auto, 0 off, 1 on
     hipStream_t s_cap = nullptr;
@@ -756,6 +759,12 @@ int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int6
     return sp_all_to_all(h, ln, send, recv, bytes_per_peer, "test entry");
 }
 
+int vc_sp_all_to_all_n(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, int nslab, void* stream) {
+    if (!h || chain < 0 || chain > 1 || !send || !recv || nslab < 1) return fail(h, VC_E_INVALID, "vc_sp_all_to_all_n: bad argument");
+    Lane ln; ln.idx = chain; ln.s = (hipStream_t)stream;
+    return sp_all_to_all(h, ln, send, recv, bytes_per_peer, "test entry", nslab);
+}
+
 int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream) {
     if (!h || !send || !recv) return fail(h, VC_E_INVALID, "vc_sp_all_gather: bad argument");
     Lane ln; ln.idx = 0; ln.s = (hipStream_t)stream;
@@ -1141,9 +1150,10 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     int rc = VC_OK;
     vc_engine::GraphEntry* ge = nullptr;
     if (graph_ok) {
+        const int rkey = use_res ? h->resid_B[slot] : -1;
         for (auto& g : h->graphs)
-            if (g.flags == flags && g.scale == geoada_context_scale) ge = &g;
-        if (!ge) { h->graphs.push_back({flags, geoada_context_scale, 0, nullptr, nullptr}); ge = &h->graphs.back(); }
+            if (g.flags == flags && g.scale == geoada_context_scale && g.rkey == rkey) ge = &g;
+        if (!ge) { h->graphs.push_back({flags, geoada_context_scale, rkey, 0, nullptr, nullptr}); ge = &h->graphs.back(); }
     }
     if (ge && ge->seen == 1 && !ge->exec) {                  // second forward with this key: capture
         bool ok = hipStreamBeginCapture(h->s_cap, hipStreamCaptureModeThreadLocal) == hipSuccess;

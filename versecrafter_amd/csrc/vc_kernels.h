@@ -64,6 +64,7 @@ struct VcAttnParams {
 };
 int vc_launch_attention(const VcAttnParams& p, hipStream_t stream);
 int vc_launch_attention_mfma16(const VcAttnParams& p, hipStream_t stream);     // attention16.hip
+int vc_launch_attention_stream(const VcAttnParams& p, hipStream_t stream);     // attention_stream.hip (5-8 key tiles, padded-key folding)
 
 // ---- row kernels --------------------------------------------------------------------------
 // y = LN(x) * (1 + scale[b]) + shift[b]        (mode 0, WT.py:591,603; head WT.py:643)

@@ -91,6 +91,12 @@ def make_groups(sp_degree: int, cfg_degree: int = 1):
     return _SP_GROUP, _BP_GROUP
 
 
+def use_groups(sp_group, bp_group):
+    """Select a pair of groups made earlier by make_groups (a program that measures several layouts on one world)."""
+    global _SP_GROUP, _BP_GROUP
+    _SP_GROUP, _BP_GROUP = sp_group, bp_group
+
+
 def get_sp_group():
     return _SP_GROUP
 
@@ -383,6 +389,46 @@ class SequenceParallel:
     def comm_ranks(self, lib, handle) -> int:
         """World size the engine's RCCL communicator reports (ncclCommCount); 0 on the callback transport."""
         return int(lib.vc_sp_comm_ranks(handle))
+
+    def observed_ranks(self, handle, device) -> int:
+        """Ranks counted BY the transport: ncclCommCount of the engine's communicator ("rccl"); on the torch transport the sum
+        of an all-reduce of ones over the lane group the exchanges run on (RCCL when the group has it, else gloo)."""
+        if self.transport == "rccl":
+            return self.comm_ranks(_lib.load(), handle)
+        if self.world_size == 1:
+            return 1
+        grp = self._lane_groups[-1]
+        on_device = torch.device(device).type == "cuda" and dist.get_backend(grp) != "gloo"
+        one = torch.ones(1, dtype=torch.float32, device=device if on_device else "cpu")
+        dist.all_reduce(one, group=grp)
+        return int(round(float(one.item())))
+
+    def probe(self, lib, handle, device) -> dict:
+        """One small all-to-all on each chain's communicator and one all-gather through the ENGINE's own entry points
+        (vc_sp_all_to_all / vc_sp_all_gather: the calls the step path makes), with the payload checked: slice r of what rank
+        `me` receives must be what rank r addressed to `me`.  Raises on a wrong byte; a transport that hangs here hangs inside
+        the supervised bring-up window of bench.py, not in the timed region."""
+        P, me, n = self.world_size, self.rank, 128                         # n bf16 elements per peer
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            for chain in (0, 1):                      # two slabs per exchange: the grouped form the step path uses
+                base = torch.arange(P, device=device, dtype=torch.float32)
+                send = torch.cat([(base + me * P + 64 * chain + 32 * j).repeat_interleave(n) for j in (0, 1)]).bfloat16()
+                recv = torch.full_like(send, -1.0)
+                _lib.check(lib.vc_sp_all_to_all_n(handle, chain, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), 2 * n, 2,
+                                                  stream), handle)
+                want = torch.cat([(base * P + me + 64 * chain + 32 * j).repeat_interleave(n) for j in (0, 1)]).bfloat16()
+                if not torch.equal(recv, want):
+                    raise RuntimeError(f"sequence-parallel probe: all-to-all on chain {chain} delivered wrong data on rank {me}")
+            send = torch.full((n,), float(me), device=device).bfloat16()
+            recv = torch.full((P * n,), -1.0, device=device).bfloat16()
+            _lib.check(lib.vc_sp_all_gather(handle, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), 2 * n, stream), handle)
+            want = torch.arange(P, device=device, dtype=torch.float32).repeat_interleave(n).bfloat16()
+            if not torch.equal(recv, want):
+                raise RuntimeError(f"sequence-parallel probe: all-gather delivered wrong data on rank {me}")
+        if self.error is not None:
+            raise RuntimeError("sequence-parallel probe: a collective failed") from self.error
+        return {"ranks": self.observed_ranks(handle, device), "transport": self.transport}
 
     def _buf(self, ptr, nbytes):
         key = (ptr, nbytes)

@@ -119,7 +119,7 @@ class _NoExchange:
     world_size, rank, transport, error = 1, 0, "none", None
 
     def attach(self, lib, handle):
-        _lib.check(lib.vc_sp_init(handle, 1, 0, None, None, None), handle)
+        _lib.check(lib.vc_sp_init(handle, 1, 0, _lib.ALL_TO_ALL_FN(), _lib.ALL_GATHER_FN(), None), handle)      # NULL callbacks
 
 
 def _ident(t: torch.Tensor):
@@ -360,6 +360,20 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         lib, h = _lib.load(), self._engine_handle()
         self._attach_sp(lib, h)
         return getattr(self._sp, "transport", "none") if self._sp is not None else "none"
+
+    def probe_exchange(self, device) -> dict:
+        """One checked all-to-all per chain + one all-gather through the engine's transport (dist.SequenceParallel.probe);
+        {"ranks": what the transport counts, "transport": name}.  Communicators are attached first if they are not yet."""
+        lib, h = _lib.load(), self._engine_handle()
+        self._attach_sp(lib, h)
+        if self._sp is None or not hasattr(self._sp, "probe"):
+            return {"ranks": 0, "transport": "none"}
+        return self._sp.probe(lib, h, device)
+
+    def sp_observed_ranks(self, device) -> int:
+        if self._sp is None or not hasattr(self._sp, "observed_ranks"):
+            return 0
+        return self._sp.observed_ranks(self._engine_handle(), device)
 
     def _attach_sp(self, lib, h) -> bool:
         if not self._sp_dirty:
