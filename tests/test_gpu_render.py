@@ -187,3 +187,44 @@ def test_full_sequence_flow_runs_at_the_clip_size(CM):
     assert len(g_rgb) == F_ and float(g_a[0].max()) > 0.99 and float(g_a[0].min()) == 0.0
     out = CM.blend_gaussian_projection_with_bg(g_rgb, g_a, rgb)
     assert out[0].shape == (H, W, 3)
+
+
+def test_renderer_cli_writes_the_five_control_maps_the_inference_cli_reads(tmp_path):
+    """inference/rendering_4D_control_maps.py end to end on a synthetic scene (PNG + depth npz + object mask + camera trajectory +
+    ellipsoid json, the file set of the reference's demo_data folders): the five control videos come out under the names
+    versecrafter_inference.py looks for (CLI.py:351-403), as frame dumps when the image has no codec."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    H, W, F_ = 64, 96, 5
+    Image.fromarray(rs.randint(0, 255, (H, W, 3), dtype=np.uint8)).save(tmp_path / "0001.png")
+    np.savez(tmp_path / "0001.npz", depth=(2.0 + rs.rand(H, W)).astype(np.float32),
+             intrinsic=np.array([[0.8, 0, 0.5], [0, 1.2, 0.5], [0, 0, 1]], dtype=np.float32))
+    (tmp_path / "masks").mkdir()
+    m = np.zeros((H, W), dtype=np.uint8)
+    m[20:40, 30:60] = 255
+    Image.fromarray(m).save(tmp_path / "masks" / "obj1.png")
+    c2w = np.tile(np.eye(4), (F_, 1, 1))
+    c2w[:, :3, :3] = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=np.float64)     # Blender camera at the origin looking along world +Y, up +Z
+    c2w[:, 0, 3] = np.linspace(0, 0.1, F_)
+    np.savez(tmp_path / "custom_camera_trajectory.npz", extrinsics=c2w)
+    doc = {"metadata": {"num_frames": F_, "num_objects": 1, "obj_id_to_color_idx": {"1": 2}},
+           "frames": [{"frame_index": f, "objects": [{"object_id": 1, "gaussian_3d": {"mean": [0.05 * f, 2.0, 0.0],
+                                                                                     "covariance": [[0.02, 0, 0], [0, 0.02, 0], [0, 0, 0.03]]}}]}
+                      for f in range(F_)]}
+    (tmp_path / "ell.json").write_text(json.dumps(doc))
+    out = tmp_path / "rendering_4D_maps"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference", "rendering_4D_control_maps.py"), "--png_path", str(tmp_path / "0001.png"),
+                        "--npz_path", str(tmp_path / "0001.npz"), "--mask_dir", str(tmp_path / "masks"), "--trajectory_npz",
+                        str(tmp_path / "custom_camera_trajectory.npz"), "--ellipsoid_json", str(tmp_path / "ell.json"), "--output_dir", str(out),
+                        "--ellipsoid_subdiv", "2", "--point_size", "0.05"], capture_output=True, text=True, timeout=300)     # 1.6 px at 64 rows
+    assert r.returncode == 0, r.stderr[-3000:]
+    from versecrafter_amd.utils import video_io
+    for name in ("background_RGB", "background_depth", "3D_gaussian_RGB", "3D_gaussian_depth", "merged_mask", "background_and_3D_gaussian"):
+        v = video_io.read_video(str(out / f"{name}.mp4"), F_, (H, W))
+        assert v.shape == (1, 3, F_, H, W) and torch.isfinite(v).all(), name
+    fg = video_io.read_video(str(out / "3D_gaussian_depth.mp4"), F_, (H, W))
+    mask = video_io.read_video(str(out / "merged_mask.mp4"), F_, (H, W))
+    assert float(fg.max()) > 0.2 and 0.0 < float(mask.mean()) < 1.0           # the ellipsoid is in view; the mask has both values

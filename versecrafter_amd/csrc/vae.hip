@@ -18,6 +18,8 @@
 // (channels-last makes a pixel's channels contiguous).  The single-head attention of the middle block runs as two implicit
 // GEMMs (fp32 logits) around a softmax row kernel.  Runs once per video: ~0.15 PFLOP per encoded 81-frame 480p clip.
 #include <math.h>
+
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -193,26 +195,27 @@ __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ gamma, int64_t rows, int C, int creal,
                                                           int silu) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
     const int idx = lane * 8;
-    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (idx < C) unpack8(*(const uint4*)(x + row * C + idx), f);
-    float ss = 0.f;
+    // grid-stride over rows (a launch may not exceed 2^32 threads: 75 M rows of an 81-frame 720p activation would need 4.8e9)
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (idx < C) unpack8(*(const uint4*)(x + row * C + idx), f);
+        float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-    ss = wave_sum(ss);
-    const float sc = sqrtf((float)creal) / fmaxf(sqrtf(ss), 1e-12f);
-    if (idx < C) {
-        float g[8];
-        unpack8(*(const uint4*)(gamma + idx), g);
+        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        ss = wave_sum(ss);
+        const float sc = sqrtf((float)creal) / fmaxf(sqrtf(ss), 1e-12f);
+        if (idx < C) {
+            float g[8];
+            unpack8(*(const uint4*)(gamma + idx), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = round_bf16(f[e] * sc) * g[e];
-            if (silu) { v = round_bf16(v); v = v / (1.0f + __expf(-v)); }
-            f[e] = v;
+            for (int e = 0; e < 8; ++e) {
+                float v = round_bf16(f[e] * sc) * g[e];
+                if (silu) { v = round_bf16(v); v = v / (1.0f + __expf(-v)); }
+                f[e] = v;
+            }
+            *(uint4*)(y + row * C + idx) = pack8(f);
         }
-        *(uint4*)(y + row * C + idx) = pack8(f);
     }
 }
 
@@ -240,138 +243,152 @@ __global__ __launch_bounds__(256) void vae_softmax_kernel(const float* __restric
 __global__ __launch_bounds__(256) void vae_im2col_in_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ A, int F, int H,
                                                             int W, int cin, int Kp) {
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)F * Hp * Wp * Kp;
-    if (i >= total) return;
-    const int col = (int)(i % Kp);
-    const int64_t m = i / Kp;
-    const int wp = (int)(m % Wp), hp = (int)((m / Wp) % Hp), t = (int)(m / ((int64_t)Wp * Hp));
-    float v = 0.f;
-    if (col < 27 * cin && hp >= 1 && hp <= H && wp >= 1 && wp <= W) {
-        const int tap = col / cin, c = col - tap * cin;
-        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
-        const int tt = t + dt - 2, hh = hp - 1 + dh - 1, ww = wp - 1 + dw - 1;
-        if (tt >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W) v = (float)x[(((int64_t)c * F + tt) * H + hh) * W + ww];
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % Kp);
+        const int64_t m = i / Kp;
+        const int wp = (int)(m % Wp), hp = (int)((m / Wp) % Hp), t = (int)(m / ((int64_t)Wp * Hp));
+        float v = 0.f;
+        if (col < 27 * cin && hp >= 1 && hp <= H && wp >= 1 && wp <= W) {
+            const int tap = col / cin, c = col - tap * cin;
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const int tt = t + dt - 2, hh = hp - 1 + dh - 1, ww = wp - 1 + dw - 1;
+            if (tt >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W) v = (float)x[(((int64_t)c * F + tt) * H + hh) * W + ww];
+        }
+        A[i] = (bf16_t)v;
     }
-    A[i] = (bf16_t)v;
 }
 
 // padded channels-last -> padded channels-last, nearest 2x in space (Upsample(scale (2,2), nearest-exact)); writes all rows
 __global__ __launch_bounds__(256) void vae_upsample2x_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int T, int H,
                                                              int W, int C8) {
     const int Hp = H + 2, Wp = W + 2, H2p = 2 * H + 2, W2p = 2 * W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)T * H2p * W2p * C8;
-    if (i >= total) return;
-    const int c = (int)(i % C8);
-    const int64_t m = i / C8;
-    const int wp = (int)(m % W2p), hp = (int)((m / W2p) % H2p), t = (int)(m / ((int64_t)W2p * H2p));
-    uint4 v = uint4{0, 0, 0, 0};
-    if (hp >= 1 && hp <= 2 * H && wp >= 1 && wp <= 2 * W)
-        v = ((const uint4*)src)[(((int64_t)t * Hp + (hp - 1) / 2 + 1) * Wp + (wp - 1) / 2 + 1) * C8 + c];
-    ((uint4*)dst)[i] = v;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const int64_t m = i / C8;
+        const int wp = (int)(m % W2p), hp = (int)((m / W2p) % H2p), t = (int)(m / ((int64_t)W2p * H2p));
+        uint4 v = uint4{0, 0, 0, 0};
+        if (hp >= 1 && hp <= 2 * H && wp >= 1 && wp <= 2 * W)
+            v = ((const uint4*)src)[(((int64_t)t * Hp + (hp - 1) / 2 + 1) * Wp + (wp - 1) / 2 + 1) * C8 + c];
+        ((uint4*)dst)[i] = v;
+    }
 }
 
 // upsample3d: conv output [T1][Hp][Wp][2C] -> frames 2 j + q of dst take channels [q C, (q+1) C) of frame j
 __global__ __launch_bounds__(256) void vae_time_interleave_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int T1,
                                                                   int64_t hw, int C8) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)2 * T1 * hw * C8;
-    if (i >= total) return;
-    const int c = (int)(i % C8);
-    const int64_t m = i / C8;
-    const int64_t px = m % hw;
-    const int f = (int)(m / hw);
-    ((uint4*)dst)[i] = ((const uint4*)src)[(((int64_t)(f >> 1)) * hw + px) * (2 * C8) + (f & 1) * C8 + c];
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const int64_t m = i / C8;
+        const int64_t px = m % hw;
+        const int f = (int)(m / hw);
+        ((uint4*)dst)[i] = ((const uint4*)src)[(((int64_t)(f >> 1)) * hw + px) * (2 * C8) + (f & 1) * C8 + c];
+    }
 }
 
 // interior pixels of padded frames -> dense [T * H * W][C] and back (dst += src on scatter is not needed: the GEMM adds the residual)
 __global__ __launch_bounds__(256) void vae_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int T, int H, int W,
                                                          int C8, int scatter) {
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)T * H * W * C8;
-    if (i >= total) return;
-    const int c = (int)(i % C8);
-    const int64_t m = i / C8;
-    const int w = (int)(m % W), h = (int)((m / W) % H), t = (int)(m / ((int64_t)W * H));
-    const int64_t pi = (((int64_t)t * Hp + h + 1) * Wp + w + 1) * C8 + c;
-    if (scatter == 2) {            // dst (padded) += src (dense), bf16
-        float a[8], b[8];
-        unpack8(((const uint4*)dst)[pi], a);
-        unpack8(((const uint4*)src)[i], b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += b[e];
-        ((uint4*)dst)[pi] = pack8(a);
-    } else if (scatter) ((uint4*)dst)[pi] = ((const uint4*)src)[i];
-    else ((uint4*)dst)[i] = ((const uint4*)src)[pi];
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const int64_t m = i / C8;
+        const int w = (int)(m % W), h = (int)((m / W) % H), t = (int)(m / ((int64_t)W * H));
+        const int64_t pi = (((int64_t)t * Hp + h + 1) * Wp + w + 1) * C8 + c;
+        if (scatter == 2) {            // dst (padded) += src (dense), bf16
+            float a[8], b[8];
+            unpack8(((const uint4*)dst)[pi], a);
+            unpack8(((const uint4*)src)[i], b);
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+            ((uint4*)dst)[pi] = pack8(a);
+        } else if (scatter) ((uint4*)dst)[pi] = ((const uint4*)src)[i];
+        else ((uint4*)dst)[i] = ((const uint4*)src)[pi];
+    }
 }
 
 // dense [rows][C] -> [C][ld] (V^T of one frame for the P.V GEMM); columns >= rows zero-filled
 __global__ __launch_bounds__(256) void vae_transpose_kernel(const bf16_t* __restrict__ src, int src_ld, bf16_t* __restrict__ dst, int rows,
                                                             int C, int ld) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)C * ld) return;
-    const int col = (int)(i % ld), c = (int)(i / ld);
-    dst[i] = col < rows ? src[(int64_t)col * src_ld + c] : (bf16_t)0.f;
+    const int64_t total_ = (int64_t)C * ld;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % ld), c = (int)(i / ld);
+        dst[i] = col < rows ? src[(int64_t)col * src_ld + c] : (bf16_t)0.f;
+    }
 }
 
 // encoder tail: mu = first z channels of conv1 output (padded rows), normalised, -> [z][T][h][w] bf16
 __global__ __launch_bounds__(256) void vae_latent_out_kernel(const bf16_t* __restrict__ src, int C, bf16_t* __restrict__ out, int z, int T,
                                                              int H, int W, const float* __restrict__ mean, const float* __restrict__ inv_std) {
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)z * T * H * W) return;
-    const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % T), c = (int)(i / ((int64_t)W * H * T));
-    const float v = (float)src[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * C + c];
-    out[i] = (bf16_t)((v - mean[c]) * inv_std[c]);
+    const int64_t total_ = (int64_t)z * T * H * W;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % T), c = (int)(i / ((int64_t)W * H * T));
+        const float v = (float)src[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * C + c];
+        out[i] = (bf16_t)((v - mean[c]) * inv_std[c]);
+    }
 }
 
 // decoder head: latents [z][T][h][w] -> de-normalised, padded channels-last [T][Hp][Wp][C] (all rows written)
 __global__ __launch_bounds__(256) void vae_latent_in_kernel(const bf16_t* __restrict__ zin, bf16_t* __restrict__ dst, int C, int z, int T,
                                                             int H, int W, const float* __restrict__ mean, const float* __restrict__ inv_std) {
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)T * Hp * Wp * C) return;
-    const int c = (int)(i % C);
-    const int64_t m = i / C;
-    const int wp = (int)(m % Wp), hp = (int)((m / Wp) % Hp), t = (int)(m / ((int64_t)Wp * Hp));
-    float v = 0.f;
-    if (c < z && hp >= 1 && hp <= H && wp >= 1 && wp <= W) {
-        const float u = (float)zin[(((int64_t)c * T + t) * H + hp - 1) * W + wp - 1];
-        v = round_bf16(u / inv_std[c]) + mean[c];
+    const int64_t total_ = (int64_t)T * Hp * Wp * C;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t m = i / C;
+        const int wp = (int)(m % Wp), hp = (int)((m / Wp) % Hp), t = (int)(m / ((int64_t)Wp * Hp));
+        float v = 0.f;
+        if (c < z && hp >= 1 && hp <= H && wp >= 1 && wp <= W) {
+            const float u = (float)zin[(((int64_t)c * T + t) * H + hp - 1) * W + wp - 1];
+            v = round_bf16(u / inv_std[c]) + mean[c];
+        }
+        dst[i] = (bf16_t)v;
     }
-    dst[i] = (bf16_t)v;
 }
 
 // decoder tail: first 3 channels of the padded result, clamp(-1, 1) -> [3][F][H][W]
 __global__ __launch_bounds__(256) void vae_video_out_kernel(const bf16_t* __restrict__ src, int C, bf16_t* __restrict__ out, int F, int H,
                                                             int W) {
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)3 * F * H * W) return;
-    const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % F), c = (int)(i / ((int64_t)W * H * F));
-    const float v = (float)src[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * C + c];
-    out[i] = (bf16_t)fminf(1.f, fmaxf(-1.f, v));
+    const int64_t total_ = (int64_t)3 * F * H * W;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % F), c = (int)(i / ((int64_t)W * H * F));
+        const float v = (float)src[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * C + c];
+        out[i] = (bf16_t)fminf(1.f, fmaxf(-1.f, v));
+    }
 }
 
 // weight repack: upstream [Cout][Cin][kt][kh][kw] (or [Cout][Cin][kh][kw], or any trailing 1s) -> [Np][ntaps][Cp], zero padded.
 // im2col_first: the first conv's [Cout][3][3][3][3] -> [Np][Kp] with column tap * Cin + c (matches vae_im2col_in_kernel)
 __global__ __launch_bounds__(256) void vae_pack_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin,
                                                               int ntaps, int Np, int Cp, int im2col_first) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t K = im2col_first ? Cp : (int64_t)ntaps * Cp;
-    if (i >= (int64_t)Np * K) return;
-    const int n = (int)(i / K);
-    const int64_t k = i % K;
-    float v = 0.f;
-    if (n < Cout) {
-        int tap, c;
-        if (im2col_first) { tap = (int)(k / Cin); c = (int)(k % Cin); if (k >= (int64_t)ntaps * Cin) tap = -1; }
-        else { tap = (int)(k / Cp); c = (int)(k % Cp); }
-        if (tap >= 0 && tap < ntaps && c < Cin) v = (float)w[((int64_t)n * Cin + c) * ntaps + tap];
+    const int64_t total_ = (int64_t)Np * K;
+    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K);
+        const int64_t k = i % K;
+        float v = 0.f;
+        if (n < Cout) {
+            int tap, c;
+            if (im2col_first) { tap = (int)(k / Cin); c = (int)(k % Cin); if (k >= (int64_t)ntaps * Cin) tap = -1; }
+            else { tap = (int)(k / Cp); c = (int)(k % Cp); }
+            if (tap >= 0 && tap < ntaps && c < Cin) v = (float)w[((int64_t)n * Cin + c) * ntaps + tap];
+        }
+        out[i] = (bf16_t)v;
     }
-    out[i] = (bf16_t)v;
 }
 
 __global__ __launch_bounds__(256) void vae_pad_vec_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int n, int np, float fill) {
@@ -379,7 +396,8 @@ __global__ __launch_bounds__(256) void vae_pad_vec_kernel(const bf16_t* __restri
     if (i < np) out[i] = i < n ? v[i] : (bf16_t)fill;
 }
 
-inline int blocks_for(int64_t n) { return (int)((n + 255) / 256); }
+constexpr int64_t MAX_BLOCKS = 1 << 22;         // x 256 threads = 2^30 per launch; every element-wise kernel strides over the rest
+inline int blocks_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, MAX_BLOCKS); }
 inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
 }  // namespace
@@ -569,7 +587,7 @@ struct Runner {
         if (nf < 0) nf = src.T;
         if (dry) return VC_OK;
         const int64_t rows = (int64_t)nf * src.hw();
-        hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, src.frame(t0), dst.frame(t0), gamma,
+        hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)std::min<int64_t>((rows + 3) / 4, MAX_BLOCKS)), dim3(256), 0, s, src.frame(t0), dst.frame(t0), gamma,
                            rows, src.C, creal, silu);
         return rc = (hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP);
     }
@@ -887,6 +905,7 @@ int walk_encode(vc_vae* h, Runner& R, const void* x, void* out, int F, int H, in
     if (R.rc == VC_OK && !R.dry) {
         hipLaunchKernelGGL(vae_im2col_in_kernel, dim3(blocks_for((int64_t)F * a.hw() * 128)), dim3(256), 0, s, (const bf16_t*)x, a.frame(0), F, H, W,
                            3, 128);
+        if (hipGetLastError() != hipSuccess) return R.rc = vfail(h, VC_E_HIP, "vae_im2col_in_kernel: launch failed");
         ConvP g;
         memset(&g, 0, sizeof g);
         const PackedConv& w = CV(h, "encoder.conv1");
@@ -987,7 +1006,8 @@ int run_sized(vc_vae* h, hipStream_t s, Walk walk) {
         h->ws_bytes = total;
     }
     R.ws = h->ws;
-    const int rc = walk(R);
+    int rc = walk(R);
+    if (rc == VC_OK && hipGetLastError() != hipSuccess) rc = VC_E_HIP;       // a launch that was refused (grid too large ...) never goes unnoticed
     if (rc != VC_OK && h->err.empty()) return vfail(h, rc, "VAE pass failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     return rc;
 }
