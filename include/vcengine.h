@@ -267,6 +267,14 @@ int vc_vae_decode(vc_vae* h, const void* z, void* out, int T, int h_lat, int w_l
 const char* vc_vae_last_error(const vc_vae* h);
 int64_t vc_vae_workspace_bytes(const vc_vae* h);
 int vc_vae_release_workspace(vc_vae* h);
+/* The full-resolution stage of encode / decode (first conv + first residual blocks + strided conv; last upsample + last residual
+ * blocks + head) can run in TIME CHUNKS with two frames of history per causal convolution -- upstream's own execution order
+ * (per-conv feature caches), bit-identical to the whole-sequence walk, with a fraction of its workspace (an 81-frame 720p decode:
+ * 137 GiB whole, see DESIGN.md 8 for the chunked figure).  frames: -1 (default) = automatic -- chunks of VC_VAE_CHUNK_FRAMES (8) when the
+ * whole-sequence arena would exceed VC_VAE_WS_LIMIT_GB (40); 0 = never; n > 0 = always n frames.  vc_vae_last_time_chunk: what the last
+ * call used (0 = whole sequence). */
+int vc_vae_set_time_chunk(vc_vae* h, int frames);
+int vc_vae_last_time_chunk(const vc_vae* h);
 void vc_vae_destroy(vc_vae* h);
 
 /* ---- 4D control-map renderer (second half): the per-pixel stages of inference/rendering_4D_control_maps.py.

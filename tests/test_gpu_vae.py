@@ -96,12 +96,37 @@ def test_production_width_small_clip_vs_oracle():
     assert e1 < 3e-2 and e2 < 3e-2
 
 
+@pytest.mark.parametrize("chunk", [1, 3, 4, 8])
+def test_time_chunked_full_resolution_stage_is_bit_identical(chunk):
+    """The full-resolution stage in time chunks (two frames of history per causal convolution -- upstream's own execution order)
+    against the whole-sequence walk: encode of 13 frames and decode of 4 latent frames (13 output frames), chunk sizes that
+    divide the clip, leave a ragged tail, or are a single frame; the arena of the chunked walk must be the smaller one."""
+    cfg, Wf, m = make(TINY, 3)
+    g = torch.Generator().manual_seed(chunk)
+    x = (torch.rand(1, 3, 13, 32, 48, generator=g) * 2 - 1).bfloat16().cuda()
+    z = torch.randn(1, 16, 4, 4, 6, generator=g).bfloat16().cuda()
+    m.set_time_chunk(0)
+    e0, d0 = m.encode(x)[0].mode(), m.decode(z).sample
+    assert m.last_time_chunk() == 0
+    torch.cuda.synchronize()
+    ws0 = m.workspace_bytes()
+    m.release_workspace()
+    m.set_time_chunk(chunk)
+    e1 = m.encode(x)[0].mode()
+    assert m.last_time_chunk() == chunk
+    d1 = m.decode(z).sample
+    torch.cuda.synchronize()
+    assert torch.equal(e0, e1) and torch.equal(d0, d1)
+    assert m.workspace_bytes() < ws0
+    m.release_workspace()
+
+
 def test_config4_frame_size_encode_decode_properties():
     """BASELINE config 4's clip, 81 frames of 720 x 1280, through the production-width VAE (random weights; the CPU oracle is
-    out of reach at this size -- ~1.5 PFLOP): shapes, finiteness, the decoder's clamp, and a size-independent property of the
-    architecture -- the encoder is CAUSAL in time, so the first 41 frames alone must give the first 11 latent frames of the
-    whole clip bit for bit (every output row is the same sequence of operations whatever the clip length).  The workspace is
-    reported: the whole-sequence form needs five buffers of the largest activation (the 2x-upsampled 192-channel tensor)."""
+    out of reach at this size -- ~1.5 PFLOP): shapes, finiteness, the decoder's clamp, and two size-independent properties --
+    the encoder is CAUSAL in time (the first 41 frames alone give the first 11 latent frames of the whole clip bit for bit), and the
+    time-chunked walk the default policy picks at this size (workspace < 40 GB) equals the whole-sequence walk (137 GiB) bit for bit.
+    Round 3: this size first exposed launches of more than 2^32 threads, which HIP refuses -- silently, until every launch was checked."""
     cfg, Wf, m = make(dict(dim=96, z_dim=16), 11)
     g = torch.Generator().manual_seed(4)
     F, H, W = 81, 720, 1280
@@ -113,15 +138,31 @@ def test_config4_frame_size_encode_decode_properties():
     head = m.encode(x[:, :, :41].contiguous())[0].mode()
     torch.cuda.synchronize()
     assert head.shape == (1, 16, 11, H // 8, W // 8) and torch.equal(head, lat[:, :, :11])
-    del x, head
+    del head
     z = torch.randn(1, 16, 21, H // 8, W // 8, generator=g).bfloat16().cuda()
     vid = m.decode(z).sample
     torch.cuda.synchronize()
     ws_dec = m.workspace_bytes()
+    chunk = m.last_time_chunk()
     assert vid.shape == (1, 3, F, H, W) and torch.isfinite(vid.float()).all() and vid.float().abs().max() <= 1.0
     assert vid.float().std() > 0
-    print(f"config-4 clip: VAE workspace {ws_enc / 2**30:.1f} GiB after encode, {ws_dec / 2**30:.1f} GiB after decode")
-    assert ws_dec < 200 * 2**30
+    # default policy at this size: the full-resolution stage runs in time chunks and the arena stays below 40 GB ...
+    assert chunk == 8 and ws_enc < 40e9 and ws_dec < 40e9
+    # ... and gives the bytes of the whole-sequence walk (five times the memory)
+    m.release_workspace()
+    m.set_time_chunk(0)
+    vid_whole = m.decode(z).sample
+    torch.cuda.synchronize()
+    ws_whole = m.workspace_bytes()
+    assert m.last_time_chunk() == 0 and torch.equal(vid, vid_whole)
+    del vid_whole
+    m.release_workspace()
+    lat_whole = m.encode(x)[0].mode()
+    torch.cuda.synchronize()
+    ws_whole_enc = m.workspace_bytes()
+    assert torch.equal(lat, lat_whole)
+    print(f"config-4 clip: VAE workspace chunked (8 frames) {ws_enc / 2**30:.1f} GiB encode / {ws_dec / 2**30:.1f} GiB decode; "
+          f"whole sequence {ws_whole_enc / 2**30:.1f} / {ws_whole / 2**30:.1f} GiB")
     m.release_workspace()
 
 

@@ -100,6 +100,8 @@ SYMBOLS = {
     "vc_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "vc_vae_last_error": (C.c_char_p, [_P]),
     "vc_vae_workspace_bytes": (_L, [_P]),
+    "vc_vae_set_time_chunk": (_I, [_P, _I]),
+    "vc_vae_last_time_chunk": (_I, [_P]),
     "vc_vae_release_workspace": (_I, [_P]),
     "vc_vae_destroy": (None, [_P]),
     "vc_t5_create": (_I, [C.POINTER(vc_t5_config), C.POINTER(_P)]),

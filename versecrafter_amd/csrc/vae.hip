@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -241,9 +242,10 @@ __global__ __launch_bounds__(256) void vae_softmax_kernel(const float* __restric
 // video [3][F][H][W] (bf16) -> im2col of the first causal 3x3x3 conv on the padded output grid: A[(t, hp, wp)][tap * 3 + c]
 // (81 real columns of 128), zero outside the clip (front time padding, spatial border)
 __global__ __launch_bounds__(256) void vae_im2col_in_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ A, int F, int H,
-                                                            int W, int cin, int Kp) {
+                                                            int W, int cin, int Kp, int f0, int nf) {
+    // rows of frames [f0, f0 + nf) of an F-frame clip (time-chunked encode: f0 > 0; the time taps still reach back into x)
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t total = (int64_t)F * Hp * Wp * Kp;
+    const int64_t total = (int64_t)nf * Hp * Wp * Kp;
     // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % Kp);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void vae_im2col_in_kernel(const bf16_t* __rest
         if (col < 27 * cin && hp >= 1 && hp <= H && wp >= 1 && wp <= W) {
             const int tap = col / cin, c = col - tap * cin;
             const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
-            const int tt = t + dt - 2, hh = hp - 1 + dh - 1, ww = wp - 1 + dw - 1;
+            const int tt = f0 + t + dt - 2, hh = hp - 1 + dh - 1, ww = wp - 1 + dw - 1;
             if (tt >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W) v = (float)x[(((int64_t)c * F + tt) * H + hh) * W + ww];
         }
         A[i] = (bf16_t)v;
@@ -359,14 +361,14 @@ __global__ __launch_bounds__(256) void vae_latent_in_kernel(const bf16_t* __rest
 
 // decoder tail: first 3 channels of the padded result, clamp(-1, 1) -> [3][F][H][W]
 __global__ __launch_bounds__(256) void vae_video_out_kernel(const bf16_t* __restrict__ src, int C, bf16_t* __restrict__ out, int F, int H,
-                                                            int W) {
+                                                            int W, int f0, int nf) {
+    // frames [0, nf) of src -> frames [f0, f0 + nf) of the F-frame output
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t total_ = (int64_t)3 * F * H * W;
-    // grid-stride: a launch may not exceed 2^32 threads (HIP), and an 81-frame 720p activation has 9.6e9 elements
+    const int64_t total_ = (int64_t)3 * nf * H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_; i += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % F), c = (int)(i / ((int64_t)W * H * F));
+        const int w = (int)(i % W), h = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % nf), c = (int)(i / ((int64_t)W * H * nf));
         const float v = (float)src[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * C + c];
-        out[i] = (bf16_t)fminf(1.f, fmaxf(-1.f, v));
+        out[(((int64_t)c * F + f0 + t) * H + h) * W + w] = (bf16_t)fminf(1.f, fmaxf(-1.f, v));
     }
 }
 
@@ -418,6 +420,8 @@ struct vc_vae {
     std::vector<void*> owned;                                          // device allocations of packed weights
     bool packed = false;
     float *mean = nullptr, *inv_std = nullptr;
+    int time_chunk = -1;              // frames per chunk of the full-resolution stage: -1 auto (workspace limit), 0 never, n > 0 always
+    int last_chunk = 0;               // what the last encode / decode used (0 = whole sequence)
     char* ws = nullptr;               // workspace kept between calls (a video needs 4 encodes and a decode; allocating tens of
     int64_t ws_bytes = 0;             // GB costs seconds) until vc_vae_release_workspace / vc_vae_destroy
     std::string err;
@@ -498,46 +502,97 @@ void want_attn(vc_vae* h, const std::string& p, int c) {
 // zero-padded channels-last activation buffer
 struct PB {
     bf16_t* data = nullptr;      // row 0 of padded frame 0
-    int slot = -1;               // workspace slot it lives in
+    int64_t off = -1;            // its block in the workspace arena (Runner::alloc)
     int T = 0, H = 0, W = 0, C = 0;
     int64_t hw() const { return (int64_t)(H + 2) * (W + 2); }
     int64_t rows() const { return (int64_t)(T + 2) * hw(); }
     bf16_t* frame(int t) const { return data + ((int64_t)(t + 2) * hw()) * C; }       // real frame t
 };
 
+// History of a time-chunked stage: a tensor that a causal (3-tap) convolution reads -- directly or through a per-pixel norm -- needs
+// the last two frames of the PREVIOUS chunk in its two front-padding frames (upstream's per-convolution feature cache; the first
+// chunk's history is the zero padding).  Tensors are numbered in creation order, which is the same in every chunk.
+struct Hist {
+    std::vector<bf16_t*> cache;      // 2 padded frames each
+    std::vector<int64_t> off;        // their arena blocks
+    int k = 0, chunk = 0;
+};
+
 struct Runner {
     vc_vae* h;
     hipStream_t s;
     char* ws = nullptr;
-    int64_t slot_bytes = 0;
-    int nslots = 0;
-    std::vector<char> busy;
     int rc = VC_OK;
-    bool dry = false;            // sizing pass: walk the layers, record the largest buffer, launch nothing
-    int64_t need = 0;
+    bool dry = false;            // sizing pass: walk the layers, simulate the arena, launch nothing
+    // workspace arena: first fit at the lowest address over blocks of exactly the size asked for (the dry pass makes the same calls
+    // in the same order, so its high-water mark is what the real pass needs)
+    struct Blk { int64_t off, size; };
+    std::vector<Blk> used;       // sorted by offset
+    int64_t cap = 0, high = 0;
+
+    int64_t alloc(int64_t bytes) {
+        bytes = (bytes + 4095) / 4096 * 4096;
+        int64_t at = 0;
+        size_t i = 0;
+        for (; i < used.size(); ++i) {
+            if (used[i].off - at >= bytes) break;
+            at = used[i].off + used[i].size;
+        }
+        if (!dry && at + bytes > cap) { rc = VC_E_NOMEM; return -1; }
+        used.insert(used.begin() + i, Blk{at, bytes});
+        if (at + bytes > high) high = at + bytes;
+        return at;
+    }
+    void release(int64_t off) {
+        for (size_t i = 0; i < used.size(); ++i)
+            if (used[i].off == off) { used.erase(used.begin() + i); return; }
+    }
 
     int64_t guard_bytes(int W, int C) const { return (int64_t)(3 * (W + 2) + 8) * C * 2; }
-    // take a free slot and shape it; zeroes the two front-padding frames (every producer writes whole frames incl. the border)
+    // a block shaped as a padded activation; zeroes the two front-padding frames (every producer writes whole frames incl. the border)
     PB take(int T, int H, int W, int C) {
         PB b;
         b.T = T; b.H = H; b.W = W; b.C = C;
-        if (dry) {
-            const int64_t bytes = b.rows() * C * 2 + 2 * guard_bytes(W, C);
-            if (bytes > need) need = bytes;
-        }
-        for (int i = 0; i < nslots; ++i)
-            if (!busy[i]) {
-                busy[i] = 1;
-                b.slot = i;
-                b.data = dry ? nullptr : (bf16_t*)(ws + (int64_t)i * slot_bytes + guard_bytes(W, C));
-                if (!dry && hipMemsetAsync(b.data, 0, (size_t)(2 * b.hw() * C * 2), s) != hipSuccess) rc = VC_E_HIP;
-                return b;
-            }
-        rc = VC_E_NOMEM;
+        if (rc != VC_OK) return b;
+        b.off = alloc(b.rows() * C * 2 + 2 * guard_bytes(W, C));
+        if (b.off < 0) return b;
+        b.data = dry ? nullptr : (bf16_t*)(ws + b.off + guard_bytes(W, C));
+        if (!dry && hipMemsetAsync(b.data, 0, (size_t)(2 * b.hw() * C * 2), s) != hipSuccess) rc = VC_E_HIP;
         return b;
     }
     void give(const PB& b) {
-        if (b.slot >= 0 && b.slot < nslots) busy[b.slot] = 0;
+        if (b.off >= 0) release(b.off);
+    }
+    // a raw scratch block
+    char* take_bytes(int64_t bytes, int64_t* off) {
+        *off = rc == VC_OK ? alloc(bytes) : -1;
+        return (*off < 0 || dry) ? nullptr : ws + *off;
+    }
+
+    // ---- history of chunked stages ----
+    int hist_next(Hist& hs, const PB& b) {                       // the tensor's number; its cache is created in the first chunk
+        const int id = hs.k++;
+        if ((int)hs.cache.size() <= id) {
+            int64_t off;
+            char* p = take_bytes(2 * b.hw() * b.C * 2, &off);
+            hs.cache.push_back((bf16_t*)p);
+            hs.off.push_back(off);
+        }
+        return id;
+    }
+    void hist_load(Hist& hs, int id, const PB& b) {              // front-padding frames <- the previous chunk's last two frames
+        if (rc != VC_OK || dry || hs.chunk == 0) return;
+        if (hipMemcpyAsync(b.data, hs.cache[id], (size_t)(2 * b.hw() * b.C * 2), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = VC_E_HIP;
+    }
+    void hist_save(Hist& hs, int id, const PB& b) {              // padded frames [T, T + 2) = the last two of (history, chunk)
+        if (rc != VC_OK || dry) return;
+        if (hipMemcpyAsync(hs.cache[id], b.data + (int64_t)b.T * b.hw() * b.C, (size_t)(2 * b.hw() * b.C * 2), hipMemcpyDeviceToDevice, s) !=
+            hipSuccess)
+            rc = VC_E_HIP;
+    }
+    void hist_free(Hist& hs) {
+        for (int64_t o : hs.off) if (o >= 0) release(o);
+        hs.cache.clear(); hs.off.clear(); hs.k = 0; hs.chunk = 0;
     }
 
     int launch_conv(ConvP& p) {
@@ -619,6 +674,47 @@ int res_block(Runner& R, const std::string& p, PB& x, int cin, int cout) {
     return R.rc;
 }
 
+// The same block on one time chunk whose input carries its two history frames (Hist): norms run over history + chunk, the two causal
+// convolutions read the history of THEIR inputs, and each convolution output keeps / restores its own (consumes x).
+int res_block_chunked(Runner& R, const std::string& p, PB& x, int cin, int cout, Hist& hs) {
+    vc_vae* h = R.h;
+    const int T = x.T;
+    PB a = R.take(T, x.H, x.W, x.C);
+    R.norm(GM(h, p + "residual.0.gamma"), x, a, cin, 1, -2, T + 2);
+    PB b = R.take(T, x.H, x.W, pad64(cout));
+    const int idb = R.hist_next(hs, b);
+    R.hist_load(hs, idb, b);
+    R.conv(CV(h, p + "residual.2"), a, b, 1, 1, 0, T);
+    R.hist_save(hs, idb, b);
+    R.give(a);
+    PB c = R.take(T, x.H, x.W, pad64(cout));
+    R.norm(GM(h, p + "residual.3.gamma"), b, c, cout, 1, -2, T + 2);
+    PB sc = x;
+    if (cin != cout) {
+        sc = R.take(T, x.H, x.W, pad64(cout));
+        R.conv(CV(h, p + "shortcut"), x, sc, 1, 1, 0, T);
+        R.give(x);
+    }
+    R.conv(CV(h, p + "residual.6"), c, b, 1, 1, 0, T, &sc);      // b's chunk frames now hold the block's output ...
+    const int ido = R.hist_next(hs, b);
+    R.hist_load(hs, ido, b);                                     // ... and its front frames the output's history (c is already computed)
+    R.hist_save(hs, ido, b);
+    R.give(c);
+    R.give(sc);
+    x = b;
+    return R.rc;
+}
+
+// frames [f0, f0 + nf) of a whole-clip buffer as a chunk: frame(0) = X.frame(f0); its two "padding" frames are X's frames f0 - 2, f0 - 1
+// (the zero padding for f0 = 0) -- exactly the history a causal convolution needs.  Not an allocation: never give() it.
+PB chunk_view(const PB& X, int f0, int nf) {
+    PB v = X;
+    v.off = -1;
+    v.T = nf;
+    if (X.data) v.data = X.data + (int64_t)f0 * X.hw() * X.C;
+    return v;
+}
+
 // AttentionBlock: single-head attention over the h*w positions of each frame, in place on x (x += proj(attn(norm(x)))).
 // Per frame: gather the interior rows of q|k|v into a dense [L][3C] block, S = q k^T / sqrt(C) (fp32), P = softmax(S) (bf16),
 // o = P v (through v^T), y = proj(o), scatter-add into x.
@@ -630,23 +726,22 @@ int attn_block(Runner& R, const std::string& p, PB& x, int creal) {
     PB qkv = R.take(T, H, W, 3 * C);
     R.conv(CV(h, p + "to_qkv"), xn, qkv, 1, 1, 0, T);
     R.give(xn);
-    PB s1 = R.take(1, 1, 1, 64), s2 = R.take(1, 1, 1, 64);
-    if (R.rc != VC_OK) return R.rc;
-    bf16_t* qd = (bf16_t*)s1.data;                    // [L][3C]
+    const int64_t need1 = ((int64_t)L * 5 * C + (int64_t)C * Lp) * 2 + (1 << 20), need2 = (int64_t)L * Lp * 6 + (1 << 20);
+    int64_t o1, o2;
+    char* s1 = R.take_bytes(need1, &o1);
+    char* s2 = R.take_bytes(need2, &o2);
+    if (R.rc != VC_OK || R.dry) {
+        if (o1 >= 0) R.release(o1);
+        if (o2 >= 0) R.release(o2);
+        R.give(qkv);
+        return R.rc;
+    }
+    bf16_t* qd = (bf16_t*)s1;                         // [L][3C]
     bf16_t* vt = qd + (int64_t)L * 3 * C;             // [C][Lp]
     bf16_t* od = vt + (int64_t)C * Lp;                // [L][C]
     bf16_t* yd = od + (int64_t)L * C;                 // [L][C]
-    float* S = (float*)s2.data;                       // [L][Lp] fp32
+    float* S = (float*)s2;                            // [L][Lp] fp32
     bf16_t* P = (bf16_t*)(S + (int64_t)L * Lp);       // [L][Lp]
-    const int64_t need1 = ((int64_t)L * 5 * C + (int64_t)C * Lp) * 2 + (1 << 20), need2 = (int64_t)L * Lp * 6 + (1 << 20);
-    if (R.dry) {
-        if (need1 > R.need) R.need = need1;
-        if (need2 > R.need) R.need = need2;
-        R.give(s1); R.give(s2); R.give(qkv);
-        return R.rc;
-    }
-    if (need1 > R.slot_bytes || need2 > R.slot_bytes)
-        return R.rc = vfail(h, VC_E_NOMEM, "VAE attention scratch (%lld / %lld bytes) exceeds a workspace slot", (long long)need1, (long long)need2);
     const PackedConv& proj = CV(h, p + "proj");
     for (int t = 0; t < T && R.rc == VC_OK; ++t) {
         hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks_for((int64_t)L * 3 * C / 8)), dim3(256), 0, R.s, qkv.frame(t), qd, 1, H, W,
@@ -669,17 +764,26 @@ int attn_block(Runner& R, const std::string& p, PB& x, int creal) {
         hipLaunchKernelGGL(vae_gather_kernel, dim3(blocks_for((int64_t)L * C / 8)), dim3(256), 0, R.s, yd, x.frame(t), 1, H, W, C / 8, 2);
         if (hipGetLastError() != hipSuccess) R.rc = VC_E_HIP;
     }
-    R.give(s1); R.give(s2); R.give(qkv);
+    R.release(o1); R.release(o2); R.give(qkv);
     return R.rc;
 }
 
 // Resample downsample2d / downsample3d (consumes x)
+int down_temporal(Runner& R, const std::string& p, PB& y);
 int down_block(Runner& R, const std::string& p, PB& x, int c, bool temporal) {
     vc_vae* h = R.h;
     PB y = R.take(x.T, x.H / 2, x.W / 2, x.C);
     R.conv(CV(h, p + "resample.1"), x, y, 2, 1, 0, x.T);             // ZeroPad2d(0,1,0,1) + Conv2d(3, stride 2): the zero border is the padding
     R.give(x);
-    if (temporal && y.T > 1) {                                      // frame 0 passes; y_k = conv3(x_{2k-2}, x_{2k-1}, x_{2k}), k >= 1
+    if (temporal) down_temporal(R, p, y);
+    x = y;
+    (void)c;
+    return R.rc;
+}
+// the (3,1,1) stride-2 time convolution of downsample3d on a whole half-resolution clip, in place of y
+int down_temporal(Runner& R, const std::string& p, PB& y) {
+    vc_vae* h = R.h;
+    if (y.T > 1) {                                      // frame 0 passes; y_k = conv3(x_{2k-2}, x_{2k-1}, x_{2k}), k >= 1
         const int To = 1 + (y.T - 1) / 2;
         PB z = R.take(To, y.H, y.W, y.C);
         if (R.rc == VC_OK && !R.dry && hipMemcpyAsync(z.frame(0), y.frame(0), (size_t)(y.hw() * y.C * 2), hipMemcpyDeviceToDevice, R.s) != hipSuccess)
@@ -689,8 +793,6 @@ int down_block(Runner& R, const std::string& p, PB& x, int c, bool temporal) {
         R.give(y);
         y = z;
     }
-    x = y;
-    (void)c;
     return R.rc;
 }
 
@@ -840,6 +942,14 @@ int vc_vae_release_workspace(vc_vae* h) {
     return VC_OK;
 }
 
+int vc_vae_set_time_chunk(vc_vae* h, int frames) {
+    if (!h || frames < -1) return VC_E_INVALID;
+    h->time_chunk = frames;
+    return VC_OK;
+}
+
+int vc_vae_last_time_chunk(const vc_vae* h) { return h ? h->last_chunk : -1; }
+
 }  // extern "C"
 
 namespace {
@@ -895,27 +1005,66 @@ int pack_weights(vc_vae* h, hipStream_t s) {
     return VC_OK;
 }
 
-// the encoder / decoder as a walk over the layer list; run twice: dry (sizes the workspace slots) and for real
-int walk_encode(vc_vae* h, Runner& R, const void* x, void* out, int F, int H, int W) {
-    const vc_vae_config& c = h->cfg;
-    hipStream_t s = R.s;
-    // first convolution: im2col of the 3-channel clip (81 columns of 128) + one GEMM
-    PB a = R.take(F, H, W, 128);
-    PB y = R.take(F, H, W, pad64(c.dim));
+// the encoder / decoder as a walk over the layer list; run twice: dry (sizes the workspace arena) and for real.
+// chunk > 0: the full-resolution stage is walked in time chunks of that many frames (bit-identical: every output row is the same
+// sequence of operations; upstream's own execution order is chunked, oracle/vae_oracle.py shows the two forms equal).
+
+// first convolution of the encoder on frames [f0, f0 + nf): im2col of the 3-channel clip (81 columns of 128) + one GEMM into y.frame(0)
+int enc_first_conv(vc_vae* h, Runner& R, const void* x, int F, int H, int W, int f0, int nf, const PB& y) {
+    PB a = R.take(nf, H, W, 128);
     if (R.rc == VC_OK && !R.dry) {
-        hipLaunchKernelGGL(vae_im2col_in_kernel, dim3(blocks_for((int64_t)F * a.hw() * 128)), dim3(256), 0, s, (const bf16_t*)x, a.frame(0), F, H, W,
-                           3, 128);
+        hipLaunchKernelGGL(vae_im2col_in_kernel, dim3(blocks_for((int64_t)nf * a.hw() * 128)), dim3(256), 0, R.s, (const bf16_t*)x, a.frame(0), F, H,
+                           W, 3, 128, f0, nf);
         if (hipGetLastError() != hipSuccess) return R.rc = vfail(h, VC_E_HIP, "vae_im2col_in_kernel: launch failed");
         ConvP g;
         memset(&g, 0, sizeof g);
         const PackedConv& w = CV(h, "encoder.conv1");
         g.dense = 1; g.ntaps = 1; g.Hout_p = H + 2; g.Wout_p = W + 2; g.zero_border = 1; g.out_scale = 1.f;
-        g.src = a.frame(0); g.lda = 128; g.Cin = 128; g.wt = w.w; g.ldw = 128; g.bias = w.b; g.M = (int)((int64_t)F * a.hw()); g.N = w.np;
+        g.src = a.frame(0); g.lda = 128; g.Cin = 128; g.wt = w.w; g.ldw = 128; g.bias = w.b; g.M = (int)((int64_t)nf * a.hw()); g.N = w.np;
         g.dst = y.frame(0); g.dst_ld = y.C;
         R.rc = R.launch_conv(g);
     }
     R.give(a);
-    for (auto& l : enc_layers(c)) {
+    return R.rc;
+}
+
+int walk_encode(vc_vae* h, Runner& R, const void* x, void* out, int F, int H, int W, int chunk) {
+    const vc_vae_config& c = h->cfg;
+    hipStream_t s = R.s;
+    const std::vector<LayerDesc> layers = enc_layers(c);
+    size_t li = 0;
+    PB y;
+    // the full-resolution stage: first convolution, the residual blocks in front of the first downsample, its strided spatial conv
+    size_t first_down = 0;
+    while (first_down < layers.size() && layers[first_down].kind == 0) ++first_down;
+    if (chunk > 0 && chunk < F && first_down < layers.size()) {
+        const LayerDesc& dn = layers[first_down];
+        PB Yh = R.take(F, H / 2, W / 2, pad64(dn.cin));
+        Hist hs;
+        for (int f0 = 0; f0 < F && R.rc == VC_OK; f0 += chunk) {
+            const int nf = std::min(chunk, F - f0);
+            hs.k = 0;
+            PB yc = R.take(nf, H, W, pad64(c.dim));
+            const int id = R.hist_next(hs, yc);
+            R.hist_load(hs, id, yc);
+            enc_first_conv(h, R, x, F, H, W, f0, nf, yc);
+            R.hist_save(hs, id, yc);
+            for (size_t k = 0; k < first_down && R.rc == VC_OK; ++k) res_block_chunked(R, layers[k].p, yc, layers[k].cin, layers[k].cout, hs);
+            // ZeroPad2d(0,1,0,1) + Conv2d(3, stride 2): no extent in time, frames land at their place in the whole half-resolution clip
+            R.conv(CV(h, dn.p + "resample.1"), yc, Yh, 2, 1, 0, nf, nullptr, f0);
+            R.give(yc);
+            ++hs.chunk;
+        }
+        R.hist_free(hs);
+        y = Yh;
+        if (dn.kind == 2 && R.rc == VC_OK) down_temporal(R, dn.p, y);
+        li = first_down + 1;
+    } else {
+        y = R.take(F, H, W, pad64(c.dim));
+        enc_first_conv(h, R, x, F, H, W, 0, F, y);
+    }
+    for (; li < layers.size(); ++li) {
+        const LayerDesc& l = layers[li];
         if (R.rc != VC_OK) break;
         if (l.kind == 0) res_block(R, l.p, y, l.cin, l.cout);
         else down_block(R, l.p, y, l.cin, l.kind == 2);
@@ -942,7 +1091,26 @@ int walk_encode(vc_vae* h, Runner& R, const void* x, void* out, int F, int H, in
     return R.rc;
 }
 
-int walk_decode(vc_vae* h, Runner& R, const void* z, void* out, int T, int hh, int ww) {
+// decoder head on a (chunk of a) clip: RMS_norm + SiLU over history + chunk, the last causal convolution, clamp into frames [f0, f0 + T)
+int dec_head(vc_vae* h, Runner& R, const PB& y, void* out, int F, int H, int W, int f0, bool with_history) {
+    const vc_vae_config& c = h->cfg;
+    PB n = R.take(y.T, y.H, y.W, y.C);
+    if (with_history) R.norm(GM(h, "decoder.head.0.gamma"), y, n, c.dim, 1, -2, y.T + 2);
+    else R.norm(GM(h, "decoder.head.0.gamma"), y, n, c.dim, 1);
+    PB o = R.take(y.T, y.H, y.W, 64);
+    R.conv(CV(h, "decoder.head.2"), n, o, 1, 1, 0, y.T);
+    if (R.rc == VC_OK && (y.H != H || y.W != W))
+        R.rc = vfail(h, VC_E_STATE, "decoder produced %dx%d frames, expected %dx%d", y.H, y.W, H, W);
+    if (R.rc == VC_OK && !R.dry) {
+        hipLaunchKernelGGL(vae_video_out_kernel, dim3(blocks_for((int64_t)3 * y.T * H * W)), dim3(256), 0, R.s, o.frame(0), o.C, (bf16_t*)out, F, H, W,
+                           f0, y.T);
+        if (hipGetLastError() != hipSuccess) R.rc = VC_E_HIP;
+    }
+    R.give(n); R.give(o);
+    return R.rc;
+}
+
+int walk_decode(vc_vae* h, Runner& R, const void* z, void* out, int T, int hh, int ww, int chunk) {
     const vc_vae_config& c = h->cfg;
     hipStream_t s = R.s;
     const int F = 1 + 4 * (T - 1), H = 8 * hh, W = 8 * ww;
@@ -962,40 +1130,91 @@ int walk_decode(vc_vae* h, Runner& R, const void* z, void* out, int T, int hh, i
     if (R.rc == VC_OK) res_block(R, "decoder.middle.0.", y, top, top);
     if (R.rc == VC_OK) attn_block(R, "decoder.middle.1.", y, top);
     if (R.rc == VC_OK) res_block(R, "decoder.middle.2.", y, top, top);
-    for (auto& l : dec_layers(c)) {
+    const std::vector<LayerDesc> layers = dec_layers(c);
+    // the full-resolution stage = the last upsample (when it has no extent in time) and everything behind it
+    size_t last_up = layers.size();
+    for (size_t k = 0; k < layers.size(); ++k)
+        if (layers[k].kind != 0) last_up = k;
+    const bool chunked = chunk > 0 && last_up < layers.size() && layers[last_up].kind == 3;
+    const size_t whole_end = chunked ? last_up : layers.size();
+    for (size_t k = 0; k < whole_end; ++k) {
+        const LayerDesc& l = layers[k];
         if (R.rc != VC_OK) break;
         if (l.kind == 0) res_block(R, l.p, y, l.cin, l.cout);
         else up_block(R, l.p, y, l.cin, l.cout, l.kind == 4);
     }
-    if (R.rc == VC_OK) {
-        PB n = R.take(y.T, y.H, y.W, y.C);
-        R.norm(GM(h, "decoder.head.0.gamma"), y, n, c.dim, 1);
-        PB o = R.take(y.T, y.H, y.W, 64);
-        R.conv(CV(h, "decoder.head.2"), n, o, 1, 1, 0, y.T);
-        if (R.rc == VC_OK && (y.T != F || y.H != H || y.W != W))
-            R.rc = vfail(h, VC_E_STATE, "decoder produced %dx%dx%d, expected %dx%dx%d", y.T, y.H, y.W, F, H, W);
+    if (R.rc == VC_OK && y.T != F) R.rc = vfail(h, VC_E_STATE, "decoder produced %d frames, expected %d", y.T, F);
+    if (!chunked || chunk >= F) {
+        if (chunked)                                        // short clip: the rest of the layer list in one piece
+            for (size_t k = last_up; k < layers.size() && R.rc == VC_OK; ++k) {
+                const LayerDesc& l = layers[k];
+                if (l.kind == 0) res_block(R, l.p, y, l.cin, l.cout);
+                else up_block(R, l.p, y, l.cin, l.cout, false);
+            }
+        if (R.rc == VC_OK) dec_head(h, R, y, out, F, H, W, 0, false);
+        R.give(y);
+        return R.rc;
+    }
+    const LayerDesc& up = layers[last_up];
+    Hist hs;
+    for (int f0 = 0; f0 < F && R.rc == VC_OK; f0 += chunk) {
+        const int nf = std::min(chunk, F - f0);
+        hs.k = 0;
+        const PB xv = chunk_view(y, f0, nf);
+        PB u = R.take(nf, 2 * y.H, 2 * y.W, y.C);           // nearest 2x in space, then Conv2d(C -> C/2, 3): no extent in time
         if (R.rc == VC_OK && !R.dry) {
-            hipLaunchKernelGGL(vae_video_out_kernel, dim3(blocks_for((int64_t)3 * F * H * W)), dim3(256), 0, s, o.frame(0), o.C, (bf16_t*)out, F, H, W);
+            hipLaunchKernelGGL(vae_upsample2x_kernel, dim3(blocks_for((int64_t)nf * u.hw() * y.C / 8)), dim3(256), 0, s, xv.frame(0), u.frame(0), nf,
+                               y.H, y.W, y.C / 8);
             if (hipGetLastError() != hipSuccess) R.rc = VC_E_HIP;
         }
-        R.give(n); R.give(o);
+        PB yc = R.take(nf, u.H, u.W, pad64(up.cout));
+        const int id = R.hist_next(hs, yc);
+        R.hist_load(hs, id, yc);
+        R.conv(CV(h, up.p + "resample.1"), u, yc, 1, 1, 0, nf);
+        R.hist_save(hs, id, yc);
+        R.give(u);
+        for (size_t k = last_up + 1; k < layers.size() && R.rc == VC_OK; ++k) res_block_chunked(R, layers[k].p, yc, layers[k].cin, layers[k].cout, hs);
+        if (R.rc == VC_OK) dec_head(h, R, yc, out, F, H, W, f0, true);
+        R.give(yc);
+        ++hs.chunk;
     }
+    R.hist_free(hs);
     R.give(y);
     return R.rc;
 }
 
-constexpr int VAE_SLOTS = 5;     // most buffers alive at once: 4 (ResidualBlock: x, conv-1 output, its norm, shortcut)
-
+// workspace policy: the whole-sequence walk when its arena stays below the limit (VC_VAE_WS_LIMIT_GB, default 40), else the
+// full-resolution stage in chunks of VC_VAE_CHUNK_FRAMES (default 8) frames; vc_vae_set_time_chunk overrides (0 = never chunk)
 template <class Walk>
-int run_sized(vc_vae* h, hipStream_t s, Walk walk) {
-    Runner D;
-    D.h = h; D.s = s; D.dry = true; D.nslots = VAE_SLOTS; D.busy.assign(VAE_SLOTS, 0);
-    D.slot_bytes = 0;
-    { int r = walk(D); if (r != VC_OK) return r; }
+int run_sized(vc_vae* h, hipStream_t s, int frames, Walk walk) {
+    auto dry = [&](int chunk, int64_t* need) {
+        Runner D;
+        D.h = h; D.s = s; D.dry = true;
+        const int r = walk(D, chunk);
+        *need = D.high;
+        return r;
+    };
+    int chunk = 0;
+    int64_t need = 0;
+    if (h->time_chunk > 0) {
+        chunk = h->time_chunk;
+        { int r = dry(chunk, &need); if (r != VC_OK) return r; }
+    } else {
+        { int r = dry(0, &need); if (r != VC_OK) return r; }
+        const char* lim = getenv("VC_VAE_WS_LIMIT_GB");
+        const char* cf = getenv("VC_VAE_CHUNK_FRAMES");
+        const double limit = (lim && *lim ? atof(lim) : 40.0) * 1e9;
+        const int auto_chunk = cf && *cf ? atoi(cf) : 8;
+        if (h->time_chunk < 0 && (double)need > limit && auto_chunk > 0 && auto_chunk < frames) {
+            int64_t need_c = 0;
+            { int r = dry(auto_chunk, &need_c); if (r != VC_OK) return r; }
+            if (need_c < need) { need = need_c; chunk = auto_chunk; }
+        }
+    }
+    h->last_chunk = chunk;
     Runner R;
-    R.h = h; R.s = s; R.nslots = VAE_SLOTS; R.busy.assign(VAE_SLOTS, 0);
-    R.slot_bytes = (D.need + 4095) / 4096 * 4096;
-    const int64_t total = R.slot_bytes * R.nslots;
+    R.h = h; R.s = s;
+    const int64_t total = need;
     if (h->ws_bytes < total) {
         if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_bytes = 0; }
         if (hipMalloc(&h->ws, (size_t)total) != hipSuccess) {
@@ -1006,7 +1225,8 @@ int run_sized(vc_vae* h, hipStream_t s, Walk walk) {
         h->ws_bytes = total;
     }
     R.ws = h->ws;
-    int rc = walk(R);
+    R.cap = h->ws_bytes;
+    int rc = walk(R, chunk);
     if (rc == VC_OK && hipGetLastError() != hipSuccess) rc = VC_E_HIP;       // a launch that was refused (grid too large ...) never goes unnoticed
     if (rc != VC_OK && h->err.empty()) return vfail(h, rc, "VAE pass failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     return rc;
@@ -1024,7 +1244,7 @@ int vc_vae_encode(vc_vae* h, const void* x, void* out, int F, int H, int W, void
     hipStream_t s = (hipStream_t)stream;
     h->err.clear();
     { int r = pack_weights(h, s); if (r != VC_OK) return r; }
-    return run_sized(h, s, [&](Runner& R) { return walk_encode(h, R, x, out, F, H, W); });
+    return run_sized(h, s, F, [&](Runner& R, int chunk) { return walk_encode(h, R, x, out, F, H, W, chunk); });
 }
 
 // z [zc][T][h][w] bf16 (normalised latents) -> video [3][1 + 4 (T - 1)][8h][8w] bf16 clamped to [-1, 1]
@@ -1034,7 +1254,7 @@ int vc_vae_decode(vc_vae* h, const void* z, void* out, int T, int hh, int ww, vo
     hipStream_t s = (hipStream_t)stream;
     h->err.clear();
     { int r = pack_weights(h, s); if (r != VC_OK) return r; }
-    return run_sized(h, s, [&](Runner& R) { return walk_decode(h, R, z, out, T, hh, ww); });
+    return run_sized(h, s, 1 + 4 * (T - 1), [&](Runner& R, int chunk) { return walk_decode(h, R, z, out, T, hh, ww, chunk); });
 }
 
 }  // extern "C"

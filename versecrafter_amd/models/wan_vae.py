@@ -268,6 +268,15 @@ class AutoencoderKLWan(nn.Module):
                     self._raise(lib, h, rc, "vc_vae_decode")
         return DecoderOutput(out.to(z.dtype))
 
+    def set_time_chunk(self, frames: int = -1):
+        """Frames per time chunk of the full-resolution stage (vc_vae_set_time_chunk): -1 automatic (chunks of 8 when the
+        whole-sequence workspace would exceed 40 GB), 0 never, n > 0 always.  Results are bit-identical either way."""
+        _lib.check(_lib.load().vc_vae_set_time_chunk(self._sync(), int(frames)))
+        return self
+
+    def last_time_chunk(self) -> int:
+        return 0 if self._engine is None else int(_lib.load().vc_vae_last_time_chunk(self._engine))
+
     def workspace_bytes(self):
         return 0 if self._engine is None else int(_lib.load().vc_vae_workspace_bytes(self._engine))
 
