@@ -160,6 +160,33 @@ def test_self_launch_two_ranks_default_measures_both_layouts():
 
 
 @pytest.mark.gpu
+def test_driver_command_line_under_torchrun_rehearsal_on_one_gpu(tmp_path):
+    """The driver's N > 1 command line verbatim -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W -- with real rank children on this box's one GPU (gloo
+    rehearsal): every torchrun worker supervises its own rank, the children rendezvous on their own port, bring-up probes run, both
+    N = 2 layouts are timed, ONE JSON line comes out of rank 0's supervisor, and every rank leaves its stderr file."""
+    import socket
+    e = dict(os.environ, VC_BENCH_LOG_DIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny", "--backend", "gloo", "--no-cpu-baseline"], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["outputs_finite"] is True
+    assert {out["config"]["parallelism"], out["alt"][0]["parallelism"]} == {"ulysses-sp2", "cfg2 x ulysses-sp1"}
+    sp = out if out["config"]["parallelism"] == "ulysses-sp2" else out["alt"][0]
+    assert sp["rccl_observed"]["sp"]["ranks"] == 2                      # counted by a collective over the lane group (gloo here)
+    for rk in range(2):
+        assert "==== attempt 0" in (tmp_path / f"bench_n2.rank{rk}.err").read_text()
+
+
+@pytest.mark.gpu
 def test_single_rank_rccl_exchange_path_through_bench():
     """N = 1 with the N > 1 plumbing forced on (VC_BENCH_FORCE_DIST=1): process group, ncclUniqueId hand-over, the engine's
     two RCCL communicators (world 1), and the whole exchange path -- pack, ncclAllToAll, segmented attention, ncclAllToAll,
