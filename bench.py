@@ -433,10 +433,14 @@ def run_rank(args):
         for lay in layouts:                                            # process groups of every layout, created once
             groups[lay] = vdist.make_groups(lay[1], lay[0])
 
+    configured = [None]
+
     def configure(lay):
-        """Point the model at one layout's groups (communicators are created on the first use of a layout only)."""
-        if not use_dist:
+        """Point the model at one layout's groups.  A no-op when the model already is in that layout: re-enabling would make the
+        engine destroy and re-create its communicators -- a second blocking rendezvous, outside the supervised bring-up window."""
+        if not use_dist or configured[0] == lay:
             return
+        configured[0] = lay
         sp_group, bp_group = groups[lay]
         vdist.use_groups(sp_group, bp_group)
         if lay[1] == 1 and lay[0] > 1:
