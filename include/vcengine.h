@@ -170,6 +170,17 @@ int vc_op_attention_variant(const void* q, const void* k, const void* v, void* o
                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                             const int64_t* o_strides, int k_len, float scale, int variant, void* stream);
 
+/* Ring attention building blocks (the ring half of the reference's Ulysses x ring hybrid, third-party xFuserLongContextAttention bound at
+ * WT.py:907-921; CLI.py:59-62): attention over ONE block of keys that also returns, per query row, the log2-domain log-sum-exp of its
+ * logits (lse float32 [B][H][Lq]); and the merge of R such partial outputs (bf16 [B][Lq][H][128] contiguous) into
+ * out = sum_r w_r part_r, w_r = exp2(lse_r - log2 sum exp2(lse)) -- equal to attention over the concatenated keys up to bf16 rounding of
+ * the parts.  HOST arrays of R device pointers. */
+int vc_op_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Lq, int Lk,
+                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int k_len,
+                        float scale, void* stream);
+int vc_op_attention_merge(const void* const* parts, const float* const* lses, int R, void* out, int B, int H, int Lq,
+                          const int64_t* o_strides, void* stream);
+
 /* The same attention on the Ulysses receive layout (token axis in segments of seg_len tokens, one per source rank):
  * strides are {batch, token within a segment, head, segment}; token t = (t / seg_len, t % seg_len).  Lq = Lk = L. */
 int vc_op_attention_segmented(const void* q, const void* k, const void* v, void* out, int B, int H, int L,

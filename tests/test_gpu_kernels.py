@@ -333,6 +333,36 @@ def test_attention_mfma16_rescale_and_packed_layout(ops):
     assert_bf16_close(got, O.attention(qc, kc, vc, [90, 90]), ulps=3.0, atol=4e-3, what="packed mfma16")
 
 
+@pytest.mark.parametrize("B,H,Lq,blocks,last_len", [(2, 2, 200, (200, 200), 150), (1, 3, 130, (300, 300, 300), 0), (1, 1, 96, (2304, 2304), 2000),
+                                                    (2, 1, 72, (64, 64, 64, 64), 1)])
+def test_ring_attention_blocks_merge_to_full_attention(ops, B, H, Lq, blocks, last_len):
+    """Ring attention's arithmetic (the ring half of the reference's Ulysses x ring hybrid): attention over each key block with
+    its log-sum-exp, then the merge -- against the oracle's attention over the concatenated keys (same bound as test_attention), the
+    lse against torch.logsumexp; a block masked down to a few keys, and a block that sees NO key (lse = -inf) contributing nothing."""
+    rs = np.random.RandomState(Lq + sum(blocks))
+    Lk = sum(blocks)
+    q, k, v = (bf(rs_randn(rs, B, L, H, 128)) for L in (Lq, Lk, Lk))
+    k_len_total = Lk - blocks[-1] + last_len if last_len else Lk
+    want = O.attention(q.float(), k.float(), v.float(), [k_len_total] * B)
+    parts, lses, off = [], [], 0
+    for i, n in enumerate(blocks):
+        kl = last_len if (i == len(blocks) - 1 and last_len) else 0
+        o_, l_ = ops.attention_lse(dev(q), dev(k[:, off:off + n].contiguous()), dev(v[:, off:off + n].contiguous()), k_len=kl)
+        s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k[:, off:off + (kl or n)].float()) / math.sqrt(128.0)
+        ref_lse = torch.logsumexp(s, dim=-1) / math.log(2.0)
+        assert torch.allclose(l_.cpu(), ref_lse, rtol=0, atol=2e-3), float((l_.cpu() - ref_lse).abs().max())
+        parts.append(o_)
+        lses.append(l_)
+        off += n
+    # a block that saw no key at all (a ring step that holds only the padded tail): ignored by the merge
+    parts.append(torch.full_like(parts[0], 7.0))
+    lses.append(torch.full_like(lses[0], float("-inf")))
+    got = ops.attention_merge(parts, lses)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, want, ulps=4.0, atol=4e-3, what="ring merge")          # one more bf16 rounding than the single pass (the parts)
+    assert rel_l2(got, want) < 6e-3
+
+
 # ----------------------------------------------------------------------------------------- row kernels
 @pytest.mark.parametrize("dim", [256, 1536, 5120])
 def test_layernorm_modulate(ops, dim):

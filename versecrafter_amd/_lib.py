@@ -73,6 +73,8 @@ SYMBOLS = {
                              C.POINTER(_L), _I, _F, _P]),
     "vc_op_attention_variant": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                      C.POINTER(_L), _I, _F, _I, _P]),
+    "vc_op_attention_lse": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _F, _P]),
+    "vc_op_attention_merge": (_I, [C.POINTER(_P), C.POINTER(_P), _I, _P, _I, _I, _I, C.POINTER(_L), _P]),
     "vc_op_attention_segmented": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                        C.POINTER(_L), _I, _I, _F, _P]),
     "vc_op_attention_padmerge": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),

@@ -643,6 +643,10 @@ int vc_launch_attention(const VcAttnParams& p, hipStream_t stream) {
     if (span_k >= (1ll << 32) || span_v >= (1ll << 32) || p.k_ts < 0 || p.v_ts < 0) return VC_E_UNSUPPORTED;
     // 256 query rows per workgroup (8 waves) halve the K/V LDS-DMA per FLOP on long sequences; short key sequences
     // (T5 cross-attention, 512 keys) are prologue-dominated and run better with twice as many, smaller workgroups
+    if (p.lse) {          // log-sum-exp output (ring attention): the 16x16x32 kernel only, plain layout
+        if (p.seg_len != 0 || p.pad_merge || (p.o_ts | p.o_hs | p.o_bs) % 8) return VC_E_UNSUPPORTED;
+        return vc_launch_attention_mfma16(p, stream);
+    }
     if (p.pad_merge) {
         if (p.seg_len > 0 || p.k_len > 0 || p.B > 8) return VC_E_UNSUPPORTED;
         int nt_max = 0;                                  // key tiles left after folding the padded tail, worst sample

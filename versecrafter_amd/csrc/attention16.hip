@@ -71,7 +71,7 @@ VC_DEVICE void reduce4_pair(float& a, float& b) {
     b = __uint_as_float(s3[1]);
 }
 
-template <int NW>
+template <int NW, bool LSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe16_kernel(VcAttnParams p, int nQ, int nwork) {
     constexpr int QB = NW * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -341,6 +341,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe16_kernel(VcAttnParam
     }
 
     reduce4_pair<false>(l_run[0], l_run[1]);
+    if (LSE && g == 0) {        // P = exp2((s - m_run) c) and l = sum P, so sum_k exp2(s c) = l 2^(m_run c); one lane of a query's four writes it
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+            if (q_row0 + 16 * qb < p.Lq)
+                p.lse[((int64_t)b * p.H + head) * p.Lq + q_row0 + 16 * qb] = log2f(l_run[qb]) + m_run[qb] * c;
+    }
     // Epilogue: lane (i, g) holds d = 16 db + 4 g .. + 3 of query i; lanes g, g^1 hold the neighbouring 8 bytes of the same row.
     // One v_permlane16_swap per dword over a (db, db+1) pair leaves every lane with 16 contiguous bytes of one row:
     // g even -> block db, g odd -> block db + 1, at d = 16 (db + (g & 1)) + 8 (g >> 1).
@@ -361,16 +367,45 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe16_kernel(VcAttnParam
     }
 }
 
-template <int NW>
+template <int NW, bool LSE>
 int launch_attn_pipe16(const VcAttnParams& p, hipStream_t stream) {
     constexpr int QB = NW * 32;
     static std::atomic<uint64_t> attr_done{0};
-    if (!vc_set_lds_once(attr_done, (const void*)attn_fwd_pipe16_kernel<NW>, LDS_BYTES)) return VC_E_HIP;
+    if (!vc_set_lds_once(attr_done, (const void*)attn_fwd_pipe16_kernel<NW, LSE>, LDS_BYTES)) return VC_E_HIP;
     const int nQ = (p.Lq + QB - 1) / QB;
     const int nwork = p.B * p.H * nQ;
     const int grid = (nwork + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_fwd_pipe16_kernel<NW>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p, nQ, nwork);
+    hipLaunchKernelGGL((attn_fwd_pipe16_kernel<NW, LSE>), dim3(grid), dim3(NW * 64), LDS_BYTES, stream, p, nQ, nwork);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+// ring attention: the outputs of R key blocks, each normalised by its own sum, re-weighted by their share of the total
+__global__ __launch_bounds__(256) void attn_merge_kernel(VcAttnMergeParams p) {
+    const int64_t rows = (int64_t)p.B * p.Lq * p.H;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // one thread per 8 output elements
+    if (i >= rows * 16) return;
+    const int64_t row = i >> 4;
+    const int ch = (int)(i & 15);
+    const int hh = (int)(row % p.H);
+    const int64_t bq = row / p.H;
+    const int q = (int)(bq % p.Lq), b = (int)(bq / p.Lq);
+    const int64_t li = ((int64_t)b * p.H + hh) * p.Lq + q;
+    float l[8], mx = -INFINITY;
+    for (int r = 0; r < p.R; ++r) { l[r] = p.lse[r][li]; mx = fmaxf(mx, l[r]); }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0.f;
+    for (int r = 0; r < p.R; ++r) {
+        const float w = l[r] == -INFINITY ? 0.f : exp2f(l[r] - mx);
+        if (w == 0.f) continue;
+        tot += w;
+        float f[8];
+        unpack8(*(const uint4*)((const bf16_t*)p.part[r] + row * 128 + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * f[e];
+    }
+    const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    *(uint4*)((bf16_t*)p.out + (int64_t)b * p.o_bs + (int64_t)q * p.o_ts + (int64_t)hh * p.o_hs + ch * 8) = pack8(acc);
 }
 
 }  // namespace
@@ -379,5 +414,15 @@ int launch_attn_pipe16(const VcAttnParams& p, hipStream_t stream) {
 int vc_launch_attention_mfma16(const VcAttnParams& p, hipStream_t stream) {
     if (p.seg_len != 0 || p.pad_merge) return VC_E_UNSUPPORTED;
     if ((p.o_ts | p.o_hs | p.o_bs) % 8) return VC_E_UNSUPPORTED;           // 16-byte output stores
-    return p.Lk >= 2048 ? launch_attn_pipe16<8>(p, stream) : launch_attn_pipe16<4>(p, stream);
+    if (p.lse) return p.Lk >= 2048 ? launch_attn_pipe16<8, true>(p, stream) : launch_attn_pipe16<4, true>(p, stream);
+    return p.Lk >= 2048 ? launch_attn_pipe16<8, false>(p, stream) : launch_attn_pipe16<4, false>(p, stream);
+}
+
+int vc_launch_attention_merge(const VcAttnMergeParams& p, hipStream_t stream) {
+    if (p.R < 1 || p.R > 8 || !p.out || p.B <= 0 || p.H <= 0 || p.Lq <= 0 || (p.o_bs | p.o_ts | p.o_hs) % 8) return VC_E_INVALID;
+    for (int r = 0; r < p.R; ++r)
+        if (!p.part[r] || !p.lse[r]) return VC_E_INVALID;
+    const int64_t n = (int64_t)p.B * p.Lq * p.H * 16;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }

@@ -1244,6 +1244,29 @@ int vc_op_attention_variant(const void* q, const void* k, const void* v, void* o
     return vc_launch_attention(a, (hipStream_t)stream);
 }
 
+int vc_op_attention_lse(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int Lq, int Lk,
+                        const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, int k_len, float scale, void* stream) {
+    if (!qs || !ks || !vs || !os || !lse) return VC_E_INVALID;
+    VcAttnParams a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale; a.lse = lse;
+    return vc_launch_attention(a, (hipStream_t)stream);
+}
+
+int vc_op_attention_merge(const void* const* parts, const float* const* lses, int R, void* out, int B, int H, int Lq, const int64_t* os,
+                          void* stream) {
+    if (!parts || !lses || !os || R < 1 || R > 8) return VC_E_INVALID;
+    VcAttnMergeParams m;
+    memset(&m, 0, sizeof m);
+    for (int r = 0; r < R; ++r) { m.part[r] = parts[r]; m.lse[r] = lses[r]; }
+    m.R = R; m.out = out; m.o_bs = os[0]; m.o_ts = os[1]; m.o_hs = os[2]; m.B = B; m.H = H; m.Lq = Lq;
+    return vc_launch_attention_merge(m, (hipStream_t)stream);
+}
+
 int vc_op_attention_segmented(const void* q, const void* k, const void* v, void* out, int B, int H, int L,
                               const int64_t* qs, const int64_t* ks, const int64_t* vs, const int64_t* os, int seg_len,
                               int k_len, float scale, void* stream) {

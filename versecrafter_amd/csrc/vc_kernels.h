@@ -61,9 +61,20 @@ struct VcAttnParams {
     // kernel selection for tests / tuning (a launch parameter, no global state): 0 = the launcher's choice, 32 = the
     // v_mfma_f32_32x32x16_bf16 pipelined kernel, 16 = the v_mfma_f32_16x16x32_bf16 one (attention16.hip; plain layout only)
     int variant;
+    // optional: log2-domain log-sum-exp of every query row, lse[(b * H + head) * Lq + q] = log2(sum_k exp2(s_qk * scale * log2 e))
+    // (float32).  Ring attention merges the outputs of several key blocks with it; only the 16x16x32 kernel writes it (plain layout).
+    float* lse;
 };
 int vc_launch_attention(const VcAttnParams& p, hipStream_t stream);
 int vc_launch_attention_mfma16(const VcAttnParams& p, hipStream_t stream);     // attention16.hip
+// out[b, q, h, :] = sum_r w_r part_r[b, q, h, :],  w_r = exp2(lse_r - log2 sum_r' exp2(lse_r'))   (parts: bf16 [B][Lq][H][128]
+// contiguous, lse: float32 [B][H][Lq]; a block that saw no key carries lse = -inf and is ignored); out with element strides
+struct VcAttnMergeParams {
+    const void* part[8]; const float* lse[8]; int R;
+    void* out; int64_t o_bs, o_ts, o_hs;
+    int B, H, Lq;
+};
+int vc_launch_attention_merge(const VcAttnMergeParams& p, hipStream_t stream);
 int vc_launch_attention_stream(const VcAttnParams& p, hipStream_t stream);     // attention_stream.hip (5-8 key tiles, padded-key folding)
 
 // ---- row kernels --------------------------------------------------------------------------

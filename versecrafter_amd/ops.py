@@ -70,6 +70,39 @@ def attention(q, k, v, k_len=0, scale=None, out=None, variant=0):
     return out
 
 
+def attention_lse(q, k, v, k_len=0, scale=None):
+    """attention() over one block of keys -> (out [B,Lq,H,128] bf16, lse [B,H,Lq] float32: log2 of the row's sum of exp2(logit * scale * log2 e))."""
+    lib = _lib.load()
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    st = lambda t: _lib.i64x3(t.stride(0), t.stride(1), t.stride(2))
+    _lib.check(lib.vc_op_attention_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, Lq, Lk, st(q), st(k), st(v), st(out), int(k_len),
+                                       float(scale), _stream()))
+    return out, lse
+
+
+def attention_merge(parts, lses):
+    """Merge R partial attention outputs (each [B,Lq,H,128] bf16 contiguous, normalised over its own key block) with their log-sum-exps."""
+    import ctypes as C
+    lib = _lib.load()
+    R = len(parts)
+    B, Lq, H, D = parts[0].shape
+    for p_, l_ in zip(parts, lses):
+        _chk(p_, "part")
+        assert p_.is_contiguous() and l_.is_contiguous() and l_.dtype == torch.float32 and tuple(l_.shape) == (B, H, Lq)
+    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=parts[0].device)
+    pa = (C.c_void_p * R)(*[p_.data_ptr() for p_ in parts])
+    la = (C.c_void_p * R)(*[l_.data_ptr() for l_ in lses])
+    _lib.check(lib.vc_op_attention_merge(pa, la, R, _ptr(out), B, H, Lq, _lib.i64x3(out.stride(0), out.stride(1), out.stride(2)), _stream()))
+    return out
+
+
 def attention_padmerge(q, k, v, pad_from, scale=None):
     """attention() where, per batch b, the keys pad_from[b] .. Lk-1 are identical rows (zero-padded prompt positions):
     they are folded into one key with multiplicity Lk - pad_from[b].  Same result as attention(q, k, v) up to rounding."""
