@@ -104,6 +104,21 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
  *   vc_sp_all_to_all / vc_sp_all_gather : the engine's collectives in isolation (tests): byte buffers, chain 0 or 1. */
 #define VC_RCCL_UNIQUE_ID_BYTES 128
 #define VC_SP_FORCE_EXCHANGE 1u
+/* Ulysses x ring hybrid (the reference's `--ulysses_degree U --ring_degree R`, CLI.py:59-62, inference.sh:66-67; third-party
+ * xFuserLongContextAttention bound at WT.py:907-921).  After vc_sp_init / vc_sp_init_rccl on a world of U * R ranks, vc_sp_set_ring(R)
+ * makes rank g * U + u exchange heads inside its Ulysses group of U neighbours (heads / U per rank, the group's U * Lloc tokens) and
+ * pass K|V blocks round the ring of the R ranks that share u; the R partial attention outputs are merged by their log-sum-exps
+ * (vc_op_attention_lse / vc_op_attention_merge).  Needed when num_heads is not divisible by the world size (Wan2.1-1.3B: 12 heads on 8
+ * GPUs = U 4 x R 2); with R = 1 nothing changes.  On the RCCL transport both exchanges are grouped point-to-point on the world
+ * communicator (callbacks may be NULL); on the callback transport:
+ *   all_to_all_sub(ctx, send, recv, bytes_per_peer, first_rank, count, stream): slice j of send goes to rank first_rank + j, slice j of
+ *                                                                               recv comes from it (count slices);
+ *   sendrecv(ctx, send, dst_rank, recv, src_rank, bytes, stream).
+ * vc_sp_init* reset the ring degree to 1. */
+typedef int (*vc_all_to_all_sub_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_peer, int first_rank, int count, void* stream);
+typedef int (*vc_sendrecv_fn)(void* ctx, const void* send, int dst_rank, void* recv, int src_rank, int64_t bytes, void* stream);
+int vc_sp_set_ring(vc_engine* h, int ring_degree, vc_all_to_all_sub_fn all_to_all_sub, vc_sendrecv_fn sendrecv);
+int vc_sp_ring_degree(const vc_engine* h);
 int vc_rccl_available(void);      /* 0 when librccl can be bound on this rank (no device work): lets the ranks AGREE, before the
                                    * first step that can fail on one side only, whether the engine-owned transport is usable */
 int vc_rccl_unique_id(void* out, int nbytes);

@@ -41,6 +41,8 @@ class vc_t5_config(C.Structure):
 
 ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALL_TO_ALL_SUB_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p)
 
 # every symbol include/vcengine.h declares: name -> (restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -53,6 +55,8 @@ SYMBOLS = {
     "vc_missing_weights": (_I, [_P]),
     "vc_set_rope_table": (_I, [_P, C.POINTER(C.c_double), _I, _I]),
     "vc_sp_init": (_I, [_P, _I, _I, ALL_TO_ALL_FN, ALL_GATHER_FN, _P]),
+    "vc_sp_set_ring": (_I, [_P, _I, ALL_TO_ALL_SUB_FN, SENDRECV_FN]),
+    "vc_sp_ring_degree": (_I, [_P]),
     "vc_rccl_available": (_I, []),
     "vc_rccl_unique_id": (_I, [_P, _I]),
     "vc_sp_init_rccl": (_I, [_P, _I, _I, _P, _I, C.c_uint32]),

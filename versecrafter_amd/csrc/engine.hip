@@ -82,6 +82,9 @@ struct Lane {
     hipStream_t comm = nullptr;     // exchanges run here (ordered against `s` by ev[]); nullptr: on `s` itself
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
+    // Ulysses x ring hybrid (ring > 1): second K|V block buffer, the R partial outputs and their log-sum-exps; ring events
+    void *kv2 = nullptr, *opart = nullptr, *lsep = nullptr;
+    hipEvent_t rev[3] = {nullptr, nullptr, nullptr};       // 0, 1: attention has finished reading K|V buffer 0 / 1; 2: ring pass landed
 };
 
 }  // namespace
@@ -109,6 +112,13 @@ struct vc_engine {
     vc_all_to_all_fn a2a = nullptr; // callback transport (vc_sp_init): tests / hosts that bring their own collective
     vc_all_gather_fn ag = nullptr;
     void* cb_ctx = nullptr;
+    // Ulysses x ring hybrid (vc_sp_set_ring): P = U * ring ranks; rank = g * U + u.  The Ulysses all-to-all runs inside the group of
+    // U neighbours that share g (heads / U per rank, the group's U * Lloc tokens), K|V blocks then travel the ring of the `ring`
+    // ranks that share u (one block = one group's tokens) and the partial outputs are merged by their log-sum-exps.  ring == 1: off.
+    int ring = 1;
+    vc_all_to_all_sub_fn a2a_sub = nullptr;      // callback transport of the hybrid's two exchanges
+    vc_sendrecv_fn sendrecv = nullptr;
+    hipEvent_t ev_ring[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
     // prepared video
     bool prepared = false;
@@ -358,6 +368,34 @@ int sp_all_gather(vc_engine* h, const Lane& lane, const void* send, void* recv, 
     return VC_OK;
 }
 
+// the hybrid's exchanges: `nslab` all-to-alls among the U ranks first .. first + U - 1 on consecutive [U][bytes_per_peer] slabs, and
+// the ring pass (send to dst, receive from src) -- on the stream `st` (the lane's exchange stream, or its compute stream)
+int sp_all_to_all_sub(vc_engine* h, const Lane& lane, hipStream_t st, const void* send, void* recv, int64_t bytes_per_peer, int nslab,
+                      int first, int count, const char* what) {
+    if (h->comm[lane.idx]) {
+        if (vc_comm_all_to_all_sub_n(h->comm[lane.idx], send, recv, bytes_per_peer, nslab, first, count, st) != VC_OK)
+            return fail(h, VC_E_HIP, "all_to_all_sub (%s): %s", what, vc_comm_error());
+        return VC_OK;
+    }
+    if (!h->a2a_sub) return fail(h, VC_E_STATE, "ring attention needs the RCCL transport or the callbacks of vc_sp_set_ring");
+    for (int j = 0; j < nslab; ++j) {
+        const int64_t off = (int64_t)j * count * bytes_per_peer;
+        if (h->a2a_sub(h->cb_ctx, (const char*)send + off, (char*)recv + off, bytes_per_peer, first, count, (void*)st) != 0)
+            return fail(h, VC_E_STATE, "all_to_all_sub callback failed (%s)", what);
+    }
+    return VC_OK;
+}
+int sp_sendrecv(vc_engine* h, const Lane& lane, hipStream_t st, const void* send, int dst, void* recv, int src, int64_t bytes) {
+    if (h->comm[lane.idx]) {
+        if (vc_comm_sendrecv(h->comm[lane.idx], send, dst, recv, src, bytes, st) != VC_OK)
+            return fail(h, VC_E_HIP, "ring pass: %s", vc_comm_error());
+        return VC_OK;
+    }
+    if (!h->sendrecv || h->sendrecv(h->cb_ctx, send, dst, recv, src, bytes, (void*)st) != 0)
+        return fail(h, VC_E_STATE, "ring pass callback failed");
+    return VC_OK;
+}
+
 // hand-over between a lane's compute stream and its exchange stream (no-ops when the exchanges run on the compute stream)
 int to_comm(vc_engine* h, Lane& ln, int k) {
     if (!ln.comm) return VC_OK;
@@ -381,6 +419,12 @@ int from_comm(vc_engine* h, Lane& ln, int k) {
 int sa_pre(vc_engine* h, Lane& ln, int B) {
     if (!h->sp_exchange) return VC_OK;
     const int Lloc = h->Lloc, P = h->P;
+    if (h->ring > 1) {         // hybrid: the same exchange inside this rank's Ulysses group of U = P / ring neighbours
+        const int U = P / h->ring;
+        const int64_t subu = (int64_t)Lloc * (h->cfg.num_heads / U) * 128;
+        { int r = to_comm(h, ln, 0); if (r != VC_OK) return r; }
+        return sp_all_to_all_sub(h, ln, ln.comm ? ln.comm : ln.s, ln.send, ln.recv, subu * 2, 3 * B, h->rank / U * U, U, "q/k/v");
+    }
     const int64_t sub = (int64_t)Lloc * (h->cfg.num_heads / P) * 128;          // elements per (tensor, sample, peer) piece
     // q|k|v are already in the exchange layout send[3][B][P_dst][Lloc][Nl][128], written there by the norm + RoPE pass.  One
     // all-to-all per (tensor, sample) slab: the pieces of one (tensor, sample) then land next to each other in source-rank =
@@ -406,6 +450,53 @@ int sa_mid(vc_engine* h, Lane& ln, int B) {
         VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
         return VC_OK;
     }
+    if (h->ring > 1) {
+        // ---- Ulysses x ring: this rank holds its group's U * Lloc tokens for N / U heads; the K|V blocks of the R groups come round
+        // the ring while the block in hand is attended to; the R partial outputs are merged by their log-sum-exps ----
+        const int R = h->ring, U = P / R, g = h->rank / U, u = h->rank % U;
+        const int Nu = N / U, Lg = U * Lloc;
+        const int64_t hdu = (int64_t)Nu * 128, slabu = (int64_t)Lg * hdu;      // one (tensor, sample): the group's tokens, Nu heads
+        hipStream_t xs = ln.comm ? ln.comm : s;
+        { int r = from_comm(h, ln, 1); if (r != VC_OK) return r; }
+        const char* rq = (const char*)ln.recv;                                 // recv: [3][B][Lg][Nu][128]
+        char* kvbuf[2] = {(char*)ln.recv + (int64_t)B * slabu * 2, (char*)ln.kv2};        // [2 (k, v)][B][Lg][Nu][128] each
+        const int64_t kvbytes = (int64_t)2 * B * slabu * 2;
+        VcAttnMergeParams mg;
+        memset(&mg, 0, sizeof mg);
+        for (int st = 0; st < R; ++st) {
+            char* cur = kvbuf[st & 1];
+            if (st + 1 < R) {          // pass the block in hand on; what arrives overwrites the buffer attention (st - 1) read
+                if (ln.comm && st >= 1) HIPCHK(h, hipStreamWaitEvent(xs, ln.rev[(st + 1) & 1], 0));
+                int r = sp_sendrecv(h, ln, xs, cur, ((g + 1) % R) * U + u, kvbuf[(st + 1) & 1], ((g + R - 1) % R) * U + u, kvbytes);
+                if (r != VC_OK) return r;
+                if (ln.comm) HIPCHK(h, hipEventRecord(ln.rev[2], xs));
+            }
+            const int gb = (g + R - st) % R;                                   // whose tokens the block in hand holds
+            int klen = h->L - gb * Lg;
+            klen = klen < 0 ? 0 : (klen > Lg ? Lg : klen);
+            char* op = (char*)ln.opart + (int64_t)st * B * slabu * 2;
+            float* lp = (float*)((char*)ln.lsep + (int64_t)st * B * Nu * Lg * 4);
+            if (klen > 0) {
+                a.q = rq; a.k = cur; a.v = cur + (int64_t)B * slabu * 2;
+                a.q_bs = a.k_bs = a.v_bs = slabu;
+                a.q_ts = a.k_ts = a.v_ts = hdu;
+                a.q_hs = a.k_hs = a.v_hs = 128;
+                a.out = op; a.o_bs = slabu; a.o_ts = hdu; a.o_hs = 128;
+                a.H = Nu; a.Lq = Lg; a.Lk = Lg; a.k_len = klen; a.lse = lp;
+                VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
+            } else {                   // only padded tokens in this block: log-sum-exp = -inf, the merge ignores it
+                HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)lp, 0xff800000u, (size_t)B * Nu * Lg, s));
+            }
+            if (ln.comm) HIPCHK(h, hipEventRecord(ln.rev[st & 1], s));
+            if (ln.comm && st + 1 < R) HIPCHK(h, hipStreamWaitEvent(s, ln.rev[2], 0));   // the next block has landed
+            mg.part[st] = op; mg.lse[st] = lp;
+        }
+        // merged output straight into the send buffer of the return exchange: [B][U_dst = token owner][Lloc][Nu][128] = [B][Lg][Nu][128]
+        mg.R = R; mg.out = ln.send; mg.o_bs = slabu; mg.o_ts = hdu; mg.o_hs = 128; mg.B = B; mg.H = Nu; mg.Lq = Lg;
+        VCCHK(h, vc_launch_attention_merge(mg, s));
+        { int r2 = to_comm(h, ln, 2); if (r2 != VC_OK) return r2; }
+        return sp_all_to_all_sub(h, ln, xs, ln.send, ln.recv, (int64_t)Lloc * hdu * 2, B, g * U, U, "o");
+    }
     // ---- Ulysses: scatter heads / gather sequence, attend over the full sequence with N/P heads, and back ----
     const int Nl = N / P;
     const int64_t hd = (int64_t)Nl * 128;            // columns per peer
@@ -429,7 +520,7 @@ int sa_post(vc_engine* h, Lane& ln, int B) {
     if (!h->sp_exchange) return VC_OK;
     { int r = from_comm(h, ln, 3); if (r != VC_OK) return r; }
     // recv: [B][P_src = head group][Lloc][Nl*128] -> attn[B*Lloc][d]
-    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * h->Lloc, h->Lloc, h->cfg.dim, h->P, ln.s));
+    VCCHK(h, vc_launch_sp_unpack_o(ln.recv, ln.attn, B * h->Lloc, h->Lloc, h->cfg.dim, h->P / h->ring, ln.s));
     return VC_OK;
 }
 
@@ -469,7 +560,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     VcRopeGrid rg{h->T, h->H2, h->W2, h->tok_off, Lloc};
     {
         ProfScope ps(h, s, VC_PROF_ROW, 0, (h->sp_exchange ? 12.0 : 8.0) * Ms * d);
-        VCCHK(h, vc_launch_qkv_front(ln.qkv, Ms, d, w.sa_nq, w.sa_nk, eps, h->rope_dev, &rg, h->sp_exchange ? ln.send : nullptr, h->P, s));
+        VCCHK(h, vc_launch_qkv_front(ln.qkv, Ms, d, w.sa_nq, w.sa_nk, eps, h->rope_dev, &rg, h->sp_exchange ? ln.send : nullptr, h->P / h->ring, s));
     }
     { int r = sa_pre(h, ln, Bs); if (r != VC_OK) return r; }
     }
@@ -627,8 +718,10 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
               hipStreamCreateWithFlags(&h->s_comm[1], hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_bp, hipEventDisableTiming) == hipSuccess;
-    for (int l = 0; ok && l < 2; ++l)
+    for (int l = 0; ok && l < 2; ++l) {
         for (int k = 0; ok && k < 4; ++k) ok = hipEventCreateWithFlags(&h->ev_lane[l][k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k < 3; ++k) ok = hipEventCreateWithFlags(&h->ev_ring[l][k], hipEventDisableTiming) == hipSuccess;
+    }
     for (size_t i = 0; ok && i < na; ++i)
         ok = hipEventCreateWithFlags(&h->ev_hint[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_used[i], hipEventDisableTiming) == hipSuccess;
@@ -644,6 +737,7 @@ void vc_destroy(vc_engine* h) {
     for (int l = 0; l < 2; ++l) {
         if (h->s_comm[l]) { (void)hipStreamSynchronize(h->s_comm[l]); (void)hipStreamDestroy(h->s_comm[l]); }
         for (int k = 0; k < 4; ++k) if (h->ev_lane[l][k]) (void)hipEventDestroy(h->ev_lane[l][k]);
+        for (int k = 0; k < 3; ++k) if (h->ev_ring[l][k]) (void)hipEventDestroy(h->ev_ring[l][k]);
     }
     if (h->ev_x) (void)hipEventDestroy(h->ev_x);
     if (h->ev_bp) (void)hipEventDestroy(h->ev_bp);
@@ -696,10 +790,9 @@ int vc_sp_init(vc_engine* h, int world, int rank, vc_all_to_all_fn a2a, vc_all_g
     if (!h) return VC_E_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(h, VC_E_INVALID, "vc_sp_init: bad world/rank");
     if (world > 1 && (!a2a || !ag)) return fail(h, VC_E_INVALID, "vc_sp_init: callbacks required for world > 1");
-    if (h->cfg.num_heads % world)
-        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     h->P = world; h->rank = rank; h->a2a = a2a; h->ag = ag; h->cb_ctx = ctx; h->sim_gbps = 0;
+    h->ring = 1; h->a2a_sub = nullptr; h->sendrecv = nullptr;
     h->sp_exchange = world > 1;
     h->prepared = false;
     return VC_OK;
@@ -722,8 +815,6 @@ int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, i
     if (!h) return VC_E_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(h, VC_E_INVALID, "vc_sp_init_rccl: bad world/rank");
     if (!unique_ids || n_ids != 2) return fail(h, VC_E_INVALID, "vc_sp_init_rccl: two unique ids required (one communicator per chain)");
-    if (h->cfg.num_heads % world)
-        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
     (void)hipStreamSynchronize(h->s_adp);
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     for (int l = 0; l < 2; ++l) {                       // same order on every rank: ncclCommInitRank is a rendezvous
@@ -734,6 +825,7 @@ int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, i
         }
     }
     h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr; h->sim_gbps = 0;
+    h->ring = 1; h->a2a_sub = nullptr; h->sendrecv = nullptr;
     h->sp_exchange = world > 1 || (flags & VC_SP_FORCE_EXCHANGE);
     h->prepared = false;
     return VC_OK;
@@ -742,14 +834,29 @@ int vc_sp_init_rccl(vc_engine* h, int world, int rank, const void* unique_ids, i
 int vc_sp_init_sim(vc_engine* h, int world, int rank, double egress_gbps) {
     if (!h) return VC_E_INVALID;
     if (world < 1 || rank < 0 || rank >= world || !(egress_gbps > 0)) return fail(h, VC_E_INVALID, "vc_sp_init_sim: bad argument");
-    if (h->cfg.num_heads % world)
-        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d must divide num_heads %d", world, h->cfg.num_heads);
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     h->P = world; h->rank = rank; h->a2a = nullptr; h->ag = nullptr; h->cb_ctx = nullptr; h->sim_gbps = egress_gbps;
+    h->ring = 1; h->a2a_sub = nullptr; h->sendrecv = nullptr;
     h->sp_exchange = true;
     h->prepared = false;
     return VC_OK;
 }
+
+int vc_sp_set_ring(vc_engine* h, int ring_degree, vc_all_to_all_sub_fn a2a_sub, vc_sendrecv_fn sendrecv) {
+    if (!h) return VC_E_INVALID;
+    if (ring_degree < 1 || ring_degree > 8 || h->P % ring_degree) return fail(h, VC_E_INVALID, "vc_sp_set_ring: ring degree %d must divide the world of %d ranks (and be <= 8)", ring_degree, h->P);
+    const int U = h->P / ring_degree;
+    if (h->cfg.num_heads % U) return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d (world %d / ring %d) must divide num_heads %d", U, h->P, ring_degree, h->cfg.num_heads);
+    if (ring_degree > 1) {
+        if (h->sim_gbps > 0) return fail(h, VC_E_UNSUPPORTED, "vc_sp_set_ring: the what-if transport has no ring exchange");
+        if (!h->comm[0] && (!a2a_sub || !sendrecv)) return fail(h, VC_E_INVALID, "vc_sp_set_ring: callbacks required without the RCCL transport");
+    }
+    h->ring = ring_degree; h->a2a_sub = a2a_sub; h->sendrecv = sendrecv;
+    h->prepared = false;
+    return VC_OK;
+}
+
+int vc_sp_ring_degree(const vc_engine* h) { return h ? h->ring : 0; }
 
 int vc_sp_comm_ranks(const vc_engine* h) { return h && h->comm[0] ? vc_comm_ranks(h->comm[0]) : 0; }
 
@@ -789,6 +896,9 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     int Lpad = seq_len;
     if (P > 1) Lpad = (seq_len + P - 1) / P * P;                                   // WT.py:195-196
     if (L > Lpad) return fail(h, VC_E_INVALID, "assert seq_lens.max() <= seq_len (WT.py:197): %d > %d", L, Lpad);
+    if (P % h->ring || c.num_heads % (P / h->ring))
+        return fail(h, VC_E_UNSUPPORTED, "Ulysses degree %d (world %d / ring %d) must divide num_heads %d: set a ring degree (vc_sp_set_ring)",
+                    P / h->ring, P, h->ring, c.num_heads);
     for (int i = 0; i < B; ++i)
         if (text_lens[i] < 0 || text_lens[i] > TL || (text_lens[i] > 0 && !text[i]))
             return fail(h, VC_E_INVALID, "prompt %d has %d tokens (text_len %d)", i, text_lens[i], TL);
@@ -813,15 +923,20 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     }
     const int nlanes = h->dual ? 2 : 1;
     const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md);
-    int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2];
+    int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2], o_kv2[2], o_opart[2], o_lsep[2];
+    const bool ringed = h->sp_exchange && h->ring > 1;
+    const int64_t lse_b = (int64_t)c.num_heads * Lloc * 4;        // log-sum-exps of one sample and one ring step: [N / U][U * Lloc] floats
     for (int l = 0; l < 2; ++l) {
         if (l < nlanes) {
             o_hint[l] = take(md); o_tb[l] = take(md); o_qkv[l] = take(3 * md); o_attn[l] = take(md);
             o_hb[l] = take((int64_t)M * f * 2); o_mod[l] = take((int64_t)B * 6 * d * 2);
             o_send[l] = take(h->sp_exchange ? 3 * md : 256); o_recv[l] = take(h->sp_exchange ? 3 * md : 256);
+            o_kv2[l] = take(ringed ? 2 * md : 256); o_opart[l] = take(ringed ? h->ring * md : 256);
+            o_lsep[l] = take(ringed ? h->ring * B * lse_b : 256);
         } else {
             o_hint[l] = o_hint[0]; o_tb[l] = o_tb[0]; o_qkv[l] = o_qkv[0]; o_attn[l] = o_attn[0]; o_hb[l] = o_hb[0];
             o_mod[l] = o_mod[0]; o_send[l] = o_send[0]; o_recv[l] = o_recv[0];
+            o_kv2[l] = o_kv2[0]; o_opart[l] = o_opart[0]; o_lsep[l] = o_lsep[0];
         }
     }
     const int kmax = (c.geoada_in_dim > c.in_dim ? c.geoada_in_dim : c.in_dim) * 4;
@@ -860,6 +975,8 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         Lane& ln = h->lane[l];
         ln.tb = a + o_tb[l]; ln.qkv = a + o_qkv[l]; ln.attn = a + o_attn[l]; ln.hb = a + o_hb[l]; ln.mod = a + o_mod[l];
         ln.send = a + o_send[l]; ln.recv = a + o_recv[l];
+        ln.kv2 = a + o_kv2[l]; ln.opart = a + o_opart[l]; ln.lsep = a + o_lsep[l];
+        for (int k = 0; k < 3; ++k) ln.rev[k] = h->ev_ring[l][k];
     }
     h->f_sin = (float*)(a + o_fsin); h->f_h = (float*)(a + o_fh); h->f_e = (float*)(a + o_fe);
     h->f_e0 = (float*)(a + o_fe0);
@@ -987,6 +1104,10 @@ static int forward_impl(vc_engine* h, const void* x, const float* t, void* out, 
                 v.attn = (char*)L0.attn + rows * d * 2; v.hb = (char*)L0.hb + rows * c.ffn_dim * 2;
                 v.mod = (char*)L0.mod + (int64_t)b * 6 * d * 2;
                 v.send = (char*)L0.send + rows * 3 * d * 2; v.recv = (char*)L0.recv + rows * 3 * d * 2;
+                // ring buffers of one sample: [2][1][..] K|V, [R][1][..] partial outputs, [R][1][..] log-sum-exps
+                v.kv2 = (char*)L0.kv2 + rows * 2 * d * 2; v.opart = (char*)L0.opart + rows * h->ring * d * 2;
+                v.lsep = (char*)L0.lsep + (int64_t)b * h->ring * c.num_heads * Lloc * 4;
+                for (int k = 0; k < 3; ++k) v.rev[k] = h->ev_ring[b][k];
             }
             if (h->lane_mode == 2) {
                 HIPCHK(h, hipEventRecord(h->ev_x, s));

@@ -213,6 +213,37 @@ int vc_comm_all_to_all_n(VcComm* c, const void* send, void* recv, int64_t bytes_
     return VC_OK;
 }
 
+// The two exchanges of the Ulysses x ring hybrid on the WORLD communicator (grouped point-to-point, one RCCL group each):
+//   sub-group all-to-all: `n` slabs of [count][bytes_per_peer]; slice j of a slab goes to rank first + j, slice j of recv comes from it;
+//   ring pass: `bytes` to rank dst, `bytes` from rank src (dst == src == own rank: a local copy).
+int vc_comm_all_to_all_sub_n(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, int n, int first, int count, hipStream_t s) {
+    const Api* a = api();
+    if (!a || !c) return VC_E_STATE;
+    if (first < 0 || count < 1 || first + count > c->world || n < 1) { t_err = "all_to_all_sub: bad rank range"; return VC_E_INVALID; }
+    if (bytes_per_peer & 1) { t_err = "all_to_all_sub: odd byte count"; return VC_E_INVALID; }
+    const size_t cnt = (size_t)bytes_per_peer / 2;
+    const int64_t slab = (int64_t)count * bytes_per_peer;
+    NCHK(a, a->GroupStart());
+    for (int j = 0; j < n; ++j)
+        for (int r = 0; r < count; ++r) {
+            NCHK_IN_GROUP(a, a->Send((const char*)send + j * slab + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, first + r, c->comm, s));
+            NCHK_IN_GROUP(a, a->Recv((char*)recv + j * slab + (int64_t)r * bytes_per_peer, cnt, ncclBfloat16, first + r, c->comm, s));
+        }
+    NCHK(a, a->GroupEnd());
+    return VC_OK;
+}
+
+int vc_comm_sendrecv(VcComm* c, const void* send, int dst, void* recv, int src, int64_t bytes, hipStream_t s) {
+    const Api* a = api();
+    if (!a || !c) return VC_E_STATE;
+    if (dst < 0 || dst >= c->world || src < 0 || src >= c->world || (bytes & 1)) { t_err = "sendrecv: bad argument"; return VC_E_INVALID; }
+    NCHK(a, a->GroupStart());
+    NCHK_IN_GROUP(a, a->Send(send, (size_t)bytes / 2, ncclBfloat16, dst, c->comm, s));
+    NCHK_IN_GROUP(a, a->Recv(recv, (size_t)bytes / 2, ncclBfloat16, src, c->comm, s));
+    NCHK(a, a->GroupEnd());
+    return VC_OK;
+}
+
 int vc_comm_all_gather(VcComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s) {
     const Api* a = api();
     if (!a || !c) return VC_E_STATE;

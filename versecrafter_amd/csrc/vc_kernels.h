@@ -138,4 +138,6 @@ void vc_comm_destroy(VcComm* c);
 int vc_comm_all_to_all(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, hipStream_t s);
 int vc_comm_all_to_all_n(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, int n, hipStream_t s);   // n slabs, one group
 int vc_comm_all_gather(VcComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s);
+int vc_comm_all_to_all_sub_n(VcComm* c, const void* send, void* recv, int64_t bytes_per_peer, int n, int first, int count, hipStream_t s);
+int vc_comm_sendrecv(VcComm* c, const void* send, int dst, void* recv, int src, int64_t bytes, hipStream_t s);
 const char* vc_comm_error();    // message of the calling thread's last failed vc_comm_* call

@@ -26,6 +26,7 @@ from . import _lib
 
 _SP_GROUP = None
 _BP_GROUP = None       # batch-parallel group (the samples of a CFG pair on different ranks); None = off
+_RING_DEGREE = 1       # the ring degree the caller asked for (set_multi_gpus_devices); see choose_ring_degree
 
 
 def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1):
@@ -37,7 +38,9 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
     data-path collective at all; only the noise prediction (4 MB at cfg-3) is all-gathered after the forward.  World size =
     cfg_degree * ulysses_degree * ring_degree; rank r works on sample r // S inside the Ulysses group of its S = ulysses * ring
     neighbours [r - r % S, r - r % S + S)."""
+    global _RING_DEGREE
     degree = int(ulysses_degree) * int(ring_degree)
+    _RING_DEGREE = int(ring_degree)
     cfg_degree = int(cfg_degree)
     world = degree * cfg_degree
     if world > 1:
@@ -49,7 +52,8 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
         if dist.get_world_size() != world:
             raise ValueError(f"cfg_degree*ulysses_degree*ring_degree = {world} but world size is {dist.get_world_size()}")
         if int(ring_degree) > 1 and dist.get_rank() == 0:
-            print(f"[versecrafter_amd] ring_degree={ring_degree} folded into a pure Ulysses degree of {degree}")
+            print(f"[versecrafter_amd] ulysses_degree={ulysses_degree} x ring_degree={ring_degree}: run as pure Ulysses of degree {degree} when the "
+                  "model's head count divides by it, else as the Ulysses x ring hybrid (dist.choose_ring_degree)")
         make_groups(degree, cfg_degree)
     local = int(os.environ.get("LOCAL_RANK", 0))
     if torch.cuda.is_available():
@@ -89,6 +93,29 @@ def make_groups(sp_degree: int, cfg_degree: int = 1):
         if me in ranks:
             _BP_GROUP = g
     return _SP_GROUP, _BP_GROUP
+
+
+def get_ring_degree() -> int:
+    return _RING_DEGREE
+
+
+def choose_ring_degree(world: int, num_heads: int, requested: int = 1) -> int:
+    """Ring degree R of a sequence-parallel world (Ulysses degree U = world / R must divide num_heads).
+    VC_SP_RING forces one (tests).  Otherwise: 1 -- pure Ulysses, two all-to-alls per attention and no partial-output merge -- whenever
+    the head count allows it (Wan2.1-14B: 40 heads, any world in {1, 2, 4, 5, 8}; this is how the reference's default 4 x 2 has always
+    been run here); else the requested degree if it is valid, else the smallest valid one (Wan2.1-1.3B, 12 heads, on 8 ranks: 2)."""
+    forced = os.environ.get("VC_SP_RING")
+    if forced:
+        r = int(forced)
+        if r < 1 or world % r or num_heads % (world // r):
+            raise ValueError(f"VC_SP_RING={r}: world {world} / ring must divide num_heads {num_heads}")
+        return r
+    if num_heads % world == 0:
+        return 1
+    valid = [r for r in range(2, min(world, 8) + 1) if world % r == 0 and num_heads % (world // r) == 0]
+    if not valid:
+        raise ValueError(f"no Ulysses x ring split of {world} ranks fits {num_heads} heads")
+    return requested if requested in valid else valid[0]
 
 
 def use_groups(sp_group, bp_group):
@@ -236,6 +263,58 @@ def ulysses_attention(q, k, v, attn_fn, group=None):
     return unpack_heads(recv2)
 
 
+def hybrid_attention(q, k, v, attn_lse_fn, ring: int, group=None, k_len=None):
+    """Reference semantics of the Ulysses x ring hybrid (third-party xFuserLongContextAttention) on local
+    [B, Lloc, N, D] tensors of rank g * U + u in a world of U * ring ranks: all-to-all inside the Ulysses group (heads scattered, the
+    group's tokens gathered), K|V blocks passed round the ring of the ranks that share u, the partial outputs merged by their
+    log-sum-exps, inverse all-to-all.  attn_lse_fn(q, k, v, k_len) -> (out [B, Lq, Nu, D], lse [B, Nu, Lq], natural log; k_len valid keys).
+    k_len: valid tokens of the whole sequence (None = all).  The CPU tests drive this with the oracle's attention."""
+    P, me = dist.get_world_size(group), dist.get_rank(group)
+    U = P // ring
+    g, u = me // U, me % U
+    B, Lloc, N, D = q.shape
+    Nu, Lg = N // U, U * Lloc
+    peers = [dist.get_global_rank(group, g * U + j) if group is not None else g * U + j for j in range(U)]
+
+    def a2a_sub(x):                                    # x [U_dst, ...] -> [U_src, ...]
+        out = torch.empty_like(x)
+        ops_ = []
+        for j in range(U):
+            if g * U + j == me:
+                out[j].copy_(x[j])
+            else:
+                ops_ += [dist.P2POp(dist.isend, x[j].contiguous(), peers[j], group), dist.P2POp(dist.irecv, out[j], peers[j], group)]
+        for w in (dist.batch_isend_irecv(ops_) if ops_ else []):
+            w.wait()
+        return out
+    send = torch.stack([q, k, v], 0).view(3, B, Lloc, U, Nu, D).permute(3, 0, 1, 2, 4, 5).contiguous()      # [U_dst, 3, B, Lloc, Nu, D]
+    recv = a2a_sub(send)                                                                                   # [U_src, 3, B, Lloc, Nu, D]
+    full = recv.permute(1, 2, 0, 3, 4, 5).reshape(3, B, Lg, Nu, D)                                         # token = src * Lloc + i
+    qg, kv = full[0], full[1:].contiguous()
+    outs, lses = [], []
+    nxt = dist.get_global_rank(group, ((g + 1) % ring) * U + u) if group is not None else ((g + 1) % ring) * U + u
+    prv = dist.get_global_rank(group, ((g - 1) % ring) * U + u) if group is not None else ((g - 1) % ring) * U + u
+    for st in range(ring):
+        gb = (g - st) % ring
+        kl = Lg if k_len is None else max(0, min(Lg, k_len - gb * Lg))
+        if kl > 0:
+            o_, l_ = attn_lse_fn(qg, kv[0], kv[1], kl)
+        else:
+            o_, l_ = torch.zeros_like(qg), torch.full((B, Nu, Lg), float("-inf"))
+        outs.append(o_)
+        lses.append(l_)
+        if st + 1 < ring:
+            got = torch.empty_like(kv)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, kv, nxt, group), dist.P2POp(dist.irecv, got, prv, group)]):
+                w.wait()
+            kv = got
+    lse = torch.stack(lses, 0)                                                   # [R, B, Nu, Lg]
+    w = torch.softmax(lse, dim=0)                                                # exp(lse_r - logsumexp)
+    o = sum(w[r].permute(0, 2, 1).unsqueeze(-1) * outs[r] for r in range(ring))  # [B, Lg, Nu, D]
+    back = a2a_sub(o.view(B, U, Lloc, Nu, D).permute(1, 0, 2, 3, 4).contiguous())             # [U_src (head group), B, Lloc, Nu, D]
+    return back.permute(1, 2, 0, 3, 4).reshape(B, Lloc, N, D)
+
+
 class _DevBuf:
     """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it (no copy)."""
 
@@ -271,7 +350,8 @@ class SequenceParallel:
             ProcessGroupNCCL runs all collectives of one group on one internal stream in issue order, so a shared group
             would make the main chain's q|k|v exchange queue behind the adapter chain's."""
 
-    def __init__(self, group=None, transport=None, force_exchange=False):
+    def __init__(self, group=None, transport=None, force_exchange=False, ring_degree=1):
+        self.ring_degree = int(ring_degree)
         self.group = group if group is not None else get_sp_group()
         if self.group is None and dist.is_initialized() and _BP_GROUP is None:
             self.group = dist.group.WORLD
@@ -295,6 +375,19 @@ class SequenceParallel:
             self._lane_groups.append(dist.new_group(ranks=ranks, backend="nccl"))     # collective: every rank gets here
         self.c_all_to_all = _lib.ALL_TO_ALL_FN(self._a2a)
         self.c_all_gather = _lib.ALL_GATHER_FN(self._ag)
+        self.c_all_to_all_sub = _lib.ALL_TO_ALL_SUB_FN(self._a2a_sub)
+        self.c_sendrecv = _lib.SENDRECV_FN(self._sendrecv)
+        if self.ring_degree < 1 or self.world_size % self.ring_degree:
+            raise ValueError(f"ring degree {self.ring_degree} must divide the sequence-parallel world of {self.world_size} ranks")
+
+    def _set_ring(self, lib, handle):
+        """Ulysses x ring hybrid (vc_sp_set_ring): on the engine-owned RCCL transport the engine does both exchanges itself
+        (grouped point-to-point on the world communicator); on the torch transport through the two callbacks below."""
+        if self.ring_degree > 1:
+            if self.transport == "rccl":
+                _lib.check(lib.vc_sp_set_ring(handle, self.ring_degree, _lib.ALL_TO_ALL_SUB_FN(), _lib.SENDRECV_FN()), handle)
+            else:
+                _lib.check(lib.vc_sp_set_ring(handle, self.ring_degree, self.c_all_to_all_sub, self.c_sendrecv), handle)
 
     def _agree(self, failed: bool) -> bool:
         """True when ANY rank of the group reports a failure (one host-side all-reduce; identity at world 1)."""
@@ -347,6 +440,7 @@ class SequenceParallel:
                     err = e
                 failed = self._agree(err is not None)                   # step 3
             if not failed:
+                self._set_ring(lib, handle)
                 return
             if self.world_size == 1 or not _group_has_rccl(self.group):
                 raise err if err is not None else RuntimeError("engine-owned RCCL transport failed on another rank")
@@ -359,6 +453,7 @@ class SequenceParallel:
                 ranks = [dist.get_global_rank(self.group, i) for i in range(self.world_size)]
                 self._lane_groups.append(dist.new_group(ranks=ranks, backend="nccl"))
         _lib.check(lib.vc_sp_init(handle, self.world_size, self.rank, self.c_all_to_all, self.c_all_gather, None), handle)
+        self._set_ring(lib, handle)
 
     def _init_rccl_with_deadline(self, lib, handle, ids, flags):
         """vc_sp_init_rccl on a helper thread; SequenceParallelStall when it has not returned within the deadline."""
@@ -468,6 +563,58 @@ class SequenceParallel:
         try:
             with self._on(stream):
                 all_gather_bytes(self._buf(send, nbytes), self._buf(recv, nbytes * self.world_size), self._group_for(stream))
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1
+
+    def _p2p(self, ops_spec, stream):
+        """[(send tensor or None, dst, recv tensor or None, src)] as one batch of point-to-point operations on the lane's group
+        (RCCL when it has it; gloo stages device buffers through host memory).  Ranks are group ranks."""
+        grp = self._group_for(stream)
+        bounce = dist.get_backend(grp) == "gloo"
+        reqs, staged = [], []
+        with self._on(stream):
+            for snd, dst, rcv, src in ops_spec:
+                if snd is not None:
+                    t = snd.cpu() if bounce else snd
+                    reqs.append(dist.P2POp(dist.isend, t, dist.get_global_rank(grp, dst), grp))
+                if rcv is not None:
+                    t = torch.empty(rcv.numel(), dtype=rcv.dtype) if bounce else rcv
+                    if bounce:
+                        staged.append((rcv, t))
+                    reqs.append(dist.P2POp(dist.irecv, t, dist.get_global_rank(grp, src), grp))
+            for w in (dist.batch_isend_irecv(reqs) if reqs else []):
+                w.wait()
+            for rcv, t in staged:
+                rcv.copy_(t)
+
+    def _a2a_sub(self, ctx, send, recv, bytes_per_peer, first, count, stream):
+        try:
+            n = bytes_per_peer * count
+            s8, r8 = self._buf(send, n), self._buf(recv, n)
+            spec = []
+            with self._on(stream):
+                for j in range(count):
+                    sl = slice(j * bytes_per_peer, (j + 1) * bytes_per_peer)
+                    if first + j == self.rank:
+                        r8[sl].copy_(s8[sl])
+                    else:
+                        spec.append((s8[sl], first + j, r8[sl], first + j))
+            self._p2p(spec, stream)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            self.error = e
+            return -1
+
+    def _sendrecv(self, ctx, send, dst, recv, src, nbytes, stream):
+        try:
+            s8, r8 = self._buf(send, nbytes), self._buf(recv, nbytes)
+            if dst == self.rank and src == self.rank:
+                with self._on(stream):
+                    r8.copy_(s8)
+            else:
+                self._p2p([(s8, dst, r8, src)], stream)
             return 0
         except Exception as e:
             self.error = e

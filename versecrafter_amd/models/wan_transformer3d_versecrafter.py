@@ -347,7 +347,15 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
                 self._sp_dirty = True
             return
         custom = hasattr(sp_group, "c_all_to_all") or hasattr(sp_group, "attach")
-        self._sp = sp_group if custom else vdist.SequenceParallel(sp_group)
+        if custom:
+            self._sp = sp_group
+        else:
+            # pure Ulysses when the head count divides by the world size, else the Ulysses x ring hybrid (dist.choose_ring_degree)
+            import torch.distributed as tdist
+            grp = sp_group if sp_group is not None else vdist.get_sp_group()
+            world = tdist.get_world_size(grp) if tdist.is_initialized() else 1
+            ring = vdist.choose_ring_degree(world, self.num_heads, vdist.get_ring_degree()) if world > 1 else 1
+            self._sp = vdist.SequenceParallel(sp_group, ring_degree=ring)
         self.sp_world_size = self._sp.world_size
         self.sp_world_rank = self._sp.rank
         self.all_gather = getattr(self._sp, "all_gather_dim1", None)
@@ -383,6 +391,8 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             sp.attach(lib, h)            # RCCL communicators inside the engine, or the callback transport
         else:                            # tests inject a bare callback object
             _lib.check(lib.vc_sp_init(h, sp.world_size, sp.rank, sp.c_all_to_all, sp.c_all_gather, None), h)
+            if getattr(sp, "ring_degree", 1) > 1:
+                _lib.check(lib.vc_sp_set_ring(h, sp.ring_degree, sp.c_all_to_all_sub, sp.c_sendrecv), h)
         self._sp_dirty = False
         self._video_key = self._video_ident = None
         return True
