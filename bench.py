@@ -139,6 +139,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cfg-degree", type=int, default=int(os.environ.get("VC_BENCH_CFG_DEGREE", "0")), choices=(0, 1, 2),
                     help="ranks that split the CFG pair (0 = auto: 2 when --gpus 2, else 1)")
+    ap.add_argument("--ring-degree", type=int, default=1,
+                    help="ring degree R of the sequence-parallel group (Ulysses x ring hybrid, the reference's --ring_degree): the Ulysses "
+                         "degree becomes ranks / R.  Default 1: pure Ulysses -- what the 14B model's 40 heads allow on 1 / 2 / 4 / 8 GPUs")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl (= RCCL; product: the engine's own communicators over xGMI) or gloo: a REHEARSAL of the N > 1 "
                          "launch on a box with fewer GPUs than ranks -- ranks share devices round-robin, exchange buffers are "
@@ -447,7 +450,7 @@ def run_rank(args):
             model.enable_multi_gpus_inference()                        # batch-parallel only: no sequence exchange
         else:
             if lay not in sps:
-                sps[lay] = vdist.SequenceParallel(sp_group, force_exchange=(world == 1))
+                sps[lay] = vdist.SequenceParallel(sp_group, force_exchange=(world == 1), ring_degree=args.ring_degree if lay[1] > 1 else 1)
             model.enable_multi_gpus_inference(sps[lay])
 
     # ---- bring-up, BEFORE any weight exists: every layout's communicators are created and each carries one probe collective;
@@ -560,7 +563,8 @@ def run_rank(args):
             else:
                 tr = "none (single rank)"
             out = {"value": sps_, "ms_per_step": 1000.0 * res["elapsed"] / args.steps,
-                   "parallelism": f"ulysses-sp{spd}" if cfgd == 1 else f"cfg{cfgd} x ulysses-sp{spd}",
+                   "parallelism": (f"ulysses-sp{spd}" if cfgd == 1 else f"cfg{cfgd} x ulysses-sp{spd}") +
+                                  (f" (ulysses {spd // args.ring_degree} x ring {args.ring_degree})" if args.ring_degree > 1 and spd > 1 else ""),
                    "cfg": "batched pair" if cfgd == 1 else "one sample per rank",
                    "step_mfma_frac": f_step * sps_ / (world * PEAK_BF16_TFLOPS * 1e12),
                    "outputs_finite": res["finite"],

@@ -129,6 +129,10 @@ int vc_sp_all_to_all(vc_engine* h, int chain, const void* send, void* recv, int6
  * transport, one callback per slab otherwise) */
 int vc_sp_all_to_all_n(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, int nslab, void* stream);
 int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream);
+/* the hybrid's two exchanges in isolation (tests, bring-up probes): nslab all-to-alls among ranks first .. first + count - 1; the ring pass */
+int vc_sp_all_to_all_sub(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, int nslab, int first, int count,
+                         void* stream);
+int vc_sp_sendrecv(vc_engine* h, int chain, const void* send, int dst_rank, void* recv, int src_rank, int64_t bytes, void* stream);
 /* What-if timing of ONE rank of a `world`-way run on a single GPU (tools/sim_sp_rank.py): every exchange is a local copy
  * followed by one idle wave that holds the chain's stream for (bytes leaving the rank) / egress_gbps -- the rank's compute
  * share, the pack / unpack passes, the two-chain schedule and the exposure of the wire time are real, the RESULTS ARE NOT

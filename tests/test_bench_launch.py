@@ -187,6 +187,18 @@ def test_driver_command_line_under_torchrun_rehearsal_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_ring_degree_rehearsal_on_one_gpu():
+    """--ring-degree 2 on two ranks (a pure ring: Ulysses degree 1): the hybrid's bring-up probe (sub-group all-to-all + ring pass through
+    the engine's entry points) and two timed steps, gloo rehearsal."""
+    r = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
+              "--cfg-degree", "1", "--ring-degree", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["config"]["parallelism"] == "ulysses-sp2 (ulysses 1 x ring 2)" and out["outputs_finite"] is True
+    assert out["rccl_observed"]["sp"]["ring_degree"] == 2 and out["rccl_observed"]["sp"]["ranks"] == 2
+
+
+@pytest.mark.gpu
 def test_single_rank_rccl_exchange_path_through_bench():
     """N = 1 with the N > 1 plumbing forced on (VC_BENCH_FORCE_DIST=1): process group, ncclUniqueId hand-over, the engine's
     two RCCL communicators (world 1), and the whole exchange path -- pack, ncclAllToAll, segmented attention, ncclAllToAll,

@@ -105,6 +105,84 @@ def test_two_process_sp_equals_single_rank_bitwise(seq_len, wide, world, lanes):
     assert all(p.exitcode == 0 for p in procs)
 
 
+HEADS6 = dict(dim=768, ffn_dim=1024, num_heads=6, num_layers=2, text_dim=64, text_len=48,
+              geoada_in_dim=128, in_dim=16, out_dim=16, freq_dim=256)
+
+
+def _worker_hybrid(rank, world, port, ulysses, ring, seq_len, q, lanes):
+    """Ulysses x ring hybrid across processes: 6 heads do not divide by 4 ranks, so set_multi_gpus_devices(2, 2) ->
+    enable_multi_gpus_inference() picks ring degree 2 by itself (dist.choose_ring_degree); the production callbacks of
+    dist.SequenceParallel carry the sub-group all-to-all and the ring pass as batched point-to-point operations (gloo, host-staged)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    if lanes is not None:
+        os.environ["VC_DUAL_LANE"] = lanes
+    if HEADS6["num_heads"] % world == 0:
+        os.environ["VC_SP_RING"] = str(ring)                    # the heads would allow pure Ulysses: force the ring (tests)
+    import torch.distributed as dist
+    from oracle import wan_oracle as O
+    from versecrafter_amd import _lib, dist as vdist
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vdist.set_multi_gpus_devices(ulysses, ring)
+        cfg = O.Config(**HEADS6)
+        W = O.random_weights(cfg, 11)
+        g = torch.Generator().manual_seed(1)
+        T, h, w = 3, 8, 12
+        x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+        geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+        ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+        t = torch.tensor([640.0, 640.0]).cuda()
+
+        def make():
+            m = VerseCrafterWanTransformer3DModel(**HEADS6)
+            m.load_state_dict(W)
+            return m.to(torch.bfloat16).to("cuda")
+        padded = (seq_len + world - 1) // world * world
+        ref = make()(x, t, geo, ctx, padded)
+        m = make()
+        m.enable_multi_gpus_inference()
+        assert m._sp.ring_degree == ring and m.sp_world_size == world
+        worst = 0.0
+        for _ in range(2):
+            out = m(x, t, geo, ctx, seq_len)
+            torch.cuda.synchronize()
+            worst = max(worst, ((out.float() - ref.float()).norm() / ref.float().norm()).item())
+        assert _lib.load().vc_sp_ring_degree(m._engine) == ring
+        q.put((rank, worst < 1e-2 and bool(torch.isfinite(out.float()).all()), worst, None))
+    except Exception as e:
+        q.put((rank, False, float("nan"), repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ulysses,ring,seq_len,lanes", [(2, 2, 72, None), (2, 2, 75, "1"), (1, 2, 72, None)])
+def test_hybrid_ulysses_ring_across_processes(ulysses, ring, seq_len, lanes):
+    """The reference's `--ulysses_degree 2 --ring_degree 2` launch shape on a model whose 6 heads do not divide by the 4 ranks (the
+    1.3B model's situation on 8 GPUs), and a pure ring of 2; one process per rank, gloo, host-staged buffers.  Tolerance as the
+    in-process hybrid test (rel L2 < 1e-2 against the single-rank engine)."""
+    world = ulysses * ring
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker_hybrid, args=(r, world, port, ulysses, ring, seq_len, q, lanes)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=300) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for rank, ok, err_rel, err in res:
+        assert err is None, (rank, err)
+        assert ok, f"rank {rank}: rel L2 {err_rel}"
+    assert all(p.exitcode == 0 for p in procs)
+
+
 def _worker_cfg(rank, world, port, sp_degree, q, teacache_cfg_skip):
     """One sample of the CFG pair per rank (dist.set_multi_gpus_devices cfg_degree = 2), Ulysses of degree sp_degree inside
     each sample's group; the per-rank outputs are gathered back into the [uncond, cond] batch."""

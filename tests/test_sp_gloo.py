@@ -150,3 +150,54 @@ def test_rccl_bring_up_failure_on_one_side_fails_on_every_rank_together(bad_rank
             assert "librccl" in outcome or "nonexistent" in outcome, res
         else:
             assert "another rank" in outcome, res
+
+
+def _hybrid_worker(rank, world, ring, port, case, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import math
+    from oracle import wan_oracle as O
+    from versecrafter_amd import dist as vdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vdist.set_multi_gpus_devices(world // ring, ring)
+        sp = vdist.SequenceParallel(ring_degree=ring)
+        fwd = load_file(os.path.join(ROOT, "tests", "golden", "forward_tiny.safetensors"))
+        cfg = O.Config(**TINY)
+        W = O.random_weights(cfg, 7)
+        ctx = [fwd["A.ctx0"], fwd["A.ctx1"]]
+        seq_len = int(fwd[f"{case}.seq_len"])
+
+        def attn_lse(q_, k_, v_, k_len):                       # attention over one key block + natural-log log-sum-exp
+            s_ = torch.einsum("bqhd,bkhd->bhqk", q_.float(), k_[:, :k_len].float()) / math.sqrt(q_.shape[-1])
+            return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, -1), v_[:, :k_len].float()), torch.logsumexp(s_, -1)
+
+        def attn_fn(q_, k_, v_, seq_lens):
+            return vdist.hybrid_attention(q_, k_, v_, attn_lse, ring, sp.group, k_len=int(seq_lens[0]))
+
+        out = O.forward(W, cfg, fwd["A.x"], fwd["A.t"], fwd["A.geoada"], ctx, seq_len, sp=(world, rank), attn_fn=attn_fn,
+                        all_gather=lambda y: sp.all_gather_dim1(y, dim=1))
+        q.put((rank, (out - fwd[f"{case}.out"]).abs().max().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world,ring", [("A", 4, 2), ("B", 4, 2), ("A", 2, 2)])
+def test_ulysses_x_ring_hybrid_equals_single_rank_golden(case, world, ring):
+    """The layout contract of the Ulysses x ring hybrid (dist.hybrid_attention: sub-group all-to-all, K|V blocks round the ring, merge by
+    log-sum-exp, inverse all-to-all) with the oracle's arithmetic in between must reproduce the reference's single-rank golden output:
+    case A: L = 72 on 4 ranks (U 2 x R 2: blocks of 36 tokens) and on a pure ring of 2; case B: seq_len 80 with the masked tail in the
+    last block."""
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_hybrid_worker, args=(r, world, ring, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err < 2e-4, (rank, err)

@@ -64,6 +64,8 @@ SYMBOLS = {
     "vc_sp_all_to_all": (_I, [_P, _I, _P, _P, _L, _P]),
     "vc_sp_all_to_all_n": (_I, [_P, _I, _P, _P, _L, _I, _P]),
     "vc_sp_all_gather": (_I, [_P, _P, _P, _L, _P]),
+    "vc_sp_all_to_all_sub": (_I, [_P, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "vc_sp_sendrecv": (_I, [_P, _I, _P, _I, _P, _I, _L, _P]),
     "vc_sp_init_sim": (_I, [_P, _I, _I, C.c_double]),
     "vc_prepare_video": (_I, [_P, _P, C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _I, _I, _I, _P]),
     "vc_forward": (_I, [_P, _P, _P, _P, _F, C.c_uint32, _P]),

@@ -872,6 +872,19 @@ int vc_sp_all_to_all_n(vc_engine* h, int chain, const void* send, void* recv, in
     return sp_all_to_all(h, ln, send, recv, bytes_per_peer, "test entry", nslab);
 }
 
+int vc_sp_all_to_all_sub(vc_engine* h, int chain, const void* send, void* recv, int64_t bytes_per_peer, int nslab, int first, int count,
+                         void* stream) {
+    if (!h || chain < 0 || chain > 1 || !send || !recv || nslab < 1) return fail(h, VC_E_INVALID, "vc_sp_all_to_all_sub: bad argument");
+    Lane ln; ln.idx = chain; ln.s = (hipStream_t)stream;
+    return sp_all_to_all_sub(h, ln, ln.s, send, recv, bytes_per_peer, nslab, first, count, "test entry");
+}
+
+int vc_sp_sendrecv(vc_engine* h, int chain, const void* send, int dst, void* recv, int src, int64_t bytes, void* stream) {
+    if (!h || chain < 0 || chain > 1 || !send || !recv) return fail(h, VC_E_INVALID, "vc_sp_sendrecv: bad argument");
+    Lane ln; ln.idx = chain; ln.s = (hipStream_t)stream;
+    return sp_sendrecv(h, ln, ln.s, send, dst, recv, src, bytes);
+}
+
 int vc_sp_all_gather(vc_engine* h, const void* send, void* recv, int64_t bytes, void* stream) {
     if (!h || !send || !recv) return fail(h, VC_E_INVALID, "vc_sp_all_gather: bad argument");
     Lane ln; ln.idx = 0; ln.s = (hipStream_t)stream;

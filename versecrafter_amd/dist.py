@@ -31,7 +31,8 @@ _RING_DEGREE = 1       # the ring degree the caller asked for (set_multi_gpus_de
 
 def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1):
     """CLI.py:180.  One process per GPU (torchrun env); returns this rank's device.  The reference's
-    ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring (head counts divide).
+    ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring when the model's head count divides by it (14B: 40 heads),
+    else as the hybrid with a ring of `ring_degree` (choose_ring_degree; the engine's vc_sp_set_ring).
 
     cfg_degree (this build; the reference has no such split): the samples of one forward's batch -- the [uncond, cond] pair of
     classifier-free guidance, PIPE.py:878-887 -- are independent units, so `cfg_degree` ranks can take one sample each with no
@@ -521,9 +522,29 @@ class SequenceParallel:
             want = torch.arange(P, device=device, dtype=torch.float32).repeat_interleave(n).bfloat16()
             if not torch.equal(recv, want):
                 raise RuntimeError(f"sequence-parallel probe: all-gather delivered wrong data on rank {me}")
+            if self.ring_degree > 1:                   # the hybrid's two exchanges: sub-group all-to-all, ring pass
+                U = P // self.ring_degree
+                g_, u_ = me // U, me % U
+                for chain in (0, 1):
+                    base = torch.arange(U, device=device, dtype=torch.float32)
+                    send = (base + u_ * U + 16 * g_ + 64 * chain).repeat_interleave(n).bfloat16()
+                    recv = torch.full_like(send, -1.0)
+                    _lib.check(lib.vc_sp_all_to_all_sub(handle, chain, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), 2 * n, 1, g_ * U,
+                                                        U, stream), handle)
+                    want = (base * U + u_ + 16 * g_ + 64 * chain).repeat_interleave(n).bfloat16()
+                    if not torch.equal(recv, want):
+                        raise RuntimeError(f"sequence-parallel probe: sub-group all-to-all on chain {chain} delivered wrong data on rank {me}")
+                    R_ = self.ring_degree
+                    send = torch.full((n,), float(me + 100 * chain), device=device).bfloat16()
+                    recv = torch.full_like(send, -1.0)
+                    src = ((g_ - 1) % R_) * U + u_
+                    _lib.check(lib.vc_sp_sendrecv(handle, chain, C.c_void_p(send.data_ptr()), ((g_ + 1) % R_) * U + u_,
+                                                  C.c_void_p(recv.data_ptr()), src, 2 * n, stream), handle)
+                    if not torch.equal(recv, torch.full((n,), float(src + 100 * chain), device=device).bfloat16()):
+                        raise RuntimeError(f"sequence-parallel probe: ring pass on chain {chain} delivered wrong data on rank {me}")
         if self.error is not None:
             raise RuntimeError("sequence-parallel probe: a collective failed") from self.error
-        return {"ranks": self.observed_ranks(handle, device), "transport": self.transport}
+        return {"ranks": self.observed_ranks(handle, device), "transport": self.transport, "ring_degree": self.ring_degree}
 
     def _buf(self, ptr, nbytes):
         key = (ptr, nbytes)
