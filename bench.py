@@ -259,6 +259,7 @@ def launch_ranks(args):
         open(pth, "w").close()
     rc_final, line = 1, None
     attempts = [None, "torch"] if os.environ.get("VC_SP_TRANSPORT") is None else [os.environ["VC_SP_TRANSPORT"]]
+    started = []                     # every child this supervisor ever started: none may outlive it, whatever goes wrong here
     try:
         for a, transport in enumerate(attempts):
             # ---- a fresh rendezvous port for the children, agreed through the board
@@ -279,6 +280,7 @@ def launch_ranks(args):
                     ef.write(f"==== attempt {a} (transport {transport or 'default: engine-owned RCCL'}) rank {r} port {port}\n")
                 outs[r] = open(os.path.join(status_dir, f"rank{r}.a{a}.out"), "w+")
                 procs[r] = subprocess.Popen(child_argv, env=env, stdout=outs[r], stderr=open(err_paths[r], "a"))
+                started.append(procs[r])
             t_spawn = time.time()
             t_all_started = None
             marked = {r: set() for r in mine}
@@ -350,6 +352,9 @@ def launch_ranks(args):
             for r in sorted(mine):
                 print(f"---- rank {r} stderr tail ({err_paths[r]}) ----\n{_tail(err_paths[r])}", file=sys.stderr)
     finally:
+        for pr in started:           # a supervisor that dies (store gone, interrupt) takes exactly its own children with it
+            if pr.poll() is None:
+                pr.kill()
         shutil.rmtree(status_dir, ignore_errors=True)
     if rc_final == 0 and line is not None:
         sys.stdout.write(line + "\n")
