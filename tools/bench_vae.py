@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the HIP Wan2.1 VAE at the bench clip's size (81 frames 480x832 -> latent [16,21,60,104]), random weights (GPU box):
-one control-video encode and one decode.   python tools/bench_vae.py [frames H W]"""
+one control-video encode and one decode.   python tools/bench_vae.py [frames H W [chunk]]"""
 import os
 import sys
 import time
@@ -70,6 +70,8 @@ def main():
             p.data.normal_(0, 1.2 / fan ** 0.5)
     x = (torch.rand(1, 3, F, H, W, device=dev) * 2 - 1).bfloat16()
     fe, fd = conv_flops(F, H, W)
+    chunk = int(sys.argv[4]) if len(sys.argv) > 4 else -1        # -1 automatic (chunks above 40 GB), 0 whole sequence, n frames per chunk
+    m.set_time_chunk(chunk)
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         z = m.encode(x)[0].mode()
@@ -78,7 +80,7 @@ def main():
         y = m.decode(z).sample
         torch.cuda.synchronize(); td = time.perf_counter() - t0
     print(f"VAE {F}x{H}x{W}: encode {te * 1e3:.0f} ms ({fe / te / 1e12:.0f} TFLOP/s of {fe / 1e12:.1f} conv TFLOP), decode {td * 1e3:.0f} ms "
-          f"({fd / td / 1e12:.0f} TFLOP/s of {fd / 1e12:.1f}), workspace {m.workspace_bytes() / 2**30:.1f} GiB, latent {tuple(z.shape)}, "
+          f"({fd / td / 1e12:.0f} TFLOP/s of {fd / 1e12:.1f}), time chunk {m.last_time_chunk()}, workspace {m.workspace_bytes() / 2**30:.1f} GiB, latent {tuple(z.shape)}, "
           f"finite {bool(torch.isfinite(y.float()).all())}")
 
 
