@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../versecrafter_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
-for f in gemm_bf16 attention norm_rope misc engine t5 sp_rccl vae; do
+for f in $(sed -n 's/^SRCS *:\?= *//p' Makefile | sed 's/\.hip//g'); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $f.hip -o $tmp/$f.o &
 done
 wait

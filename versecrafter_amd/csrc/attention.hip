@@ -250,6 +250,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
                 S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
             }
 #else
+#if VC_ATTN_ABLATE == 2        // timing ablation only (wrong results): half of the K fragment reads (= a quarter of all LDS reads) removed
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks]);
+            S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[0], 0, 0, 0);
+            S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[(ks + 1) & 7], S[1], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
                 S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
             }
         }
+#endif
 #endif
     };
     auto mask_tail = [&](f32x16 (&S)[2], int t) {      // keys >= k_len of the (last) tile t
@@ -373,8 +386,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
+#if VC_ATTN_ABLATE == 3        // timing ablation only (wrong results): K halved as in 2 AND half of the V fragment reads removed: half of all LDS reads
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][0] + (s & 1) * 4096));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][1] + (s & 1) * 4096));
+#else
                 const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][0] + s * 4096));
                 const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vbuf + lc.voff[db][1] + s * 4096));
+#endif
                 const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 O[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], O[db], 0, 0, 0);
             }
