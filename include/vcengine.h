@@ -343,6 +343,34 @@ int vc_op_render_mesh(const void* verts, const void* vert_colors, int nverts, co
                       const float* light_xyz, const float* eye_xyz, int W, int H, int background_u8, void* scratch, void* out_rgb,
                       void* out_depth, void* out_mask, void* stream);
 
+/* ---- per-object 3D Gaussian fit: pre-processing step 3, upstream of the renderer (reference inference/fit_3D_gaussian.py) ----------
+ * Device pointers unless marked HOST; pixel maps are row-major [H][W].  PINNED by the reference's own outputs for its demo clips
+ * (tests/golden/demo_fit/).  Errors: vc_fit_last_error() (thread-local text).
+ *   vc_op_fit_erode_mask   load_mask :139-159: out = (mask > 127) eroded once by cv2's ksize x ksize MORPH_ELLIPSE element (anchor at the
+ *                          centre; pixels outside the image remove nothing).  mask uint8 grey, out uint8 0 / 1.  ksize <= 31.
+ *   vc_op_fit_points       get_point_cloud_from_depth :35-92: world = c2w [K^-1 (x, y, 1) depth; 1] for the pixels whose mask is set
+ *                          (mask NULL: depth > 0), written in row-major pixel order.  kinv HOST [3][3], c2w HOST [3][4] (row-major, the
+ *                          top rows of the inverse extrinsic).  out_points float32 [H*W][3] (capacity), out_count int64 (device).
+ *   vc_op_fit_moments      fit_3d_gaussian :95-136: out12 = float32 {mean[3], cov[3][3]}, cov = centred^T centred / (n - 1) + 1e-6 I;
+ *                          fp64 accumulation in a fixed order (bit-reproducible).  n >= 3.
+ *   vc_op_fit_project      project_gaussian_to_2d :259-285: rec11 HOST = {mean_u, mean_v, inv00, inv01, inv10, inv11, coeff, min_x, max_x,
+ *                          min_y, max_y}; density = coeff exp(-m / 2), mahal = m inside [min_x, max_x) x [min_y, max_y), 0 / +inf outside
+ *                          (an empty box = a culled Gaussian).  dmax (optional, device float32): the largest density.
+ *   vc_op_fit_blend        visualize_gaussian_projections :381-397: mask = max(mask, mahal <= threshold), alpha = clamp(density / *dmax),
+ *                          picture = rgb3 alpha + picture (1 - alpha).  picture float32 [H][W][3], mask float32 [H][W], rgb3 HOST.
+ *   vc_op_fit_picture_u8   :400: uint8(clamp(x, 0, 1) 255).                                                                          */
+const char* vc_fit_last_error(void);
+int vc_op_fit_erode_mask(const void* mask_u8, void* out_u8, int W, int H, int ksize, void* stream);
+int64_t vc_op_fit_points_scratch_bytes(int W, int H);
+int vc_op_fit_points(const void* depth, const void* mask, const float* kinv, const float* c2w, int W, int H, void* scratch, void* out_points,
+                     void* out_count, void* stream);
+int64_t vc_op_fit_moments_scratch_bytes(void);
+int vc_op_fit_moments(const void* points, int64_t n, void* scratch, void* out12, void* stream);
+int vc_op_fit_project(const float* rec11, void* density, void* mahal, void* dmax, int W, int H, void* stream);
+int vc_op_fit_blend(const void* density, const void* mahal, const void* dmax, float threshold, const float* rgb3, void* picture, void* mask,
+                    int64_t npix, void* stream);
+int vc_op_fit_picture_u8(const void* src, void* dst, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,15 @@ SYMBOLS = {
     "vc_op_render_gauss_density": (_I, [_P, _I, _P, _I, _I, _P]),
     "vc_op_render_gauss_frame": (_I, [_P, _I, _P, _F, _F, _P, _P, _I, _I, _P]),
     "vc_op_render_blend": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "vc_fit_last_error": (C.c_char_p, []),
+    "vc_op_fit_erode_mask": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vc_op_fit_points_scratch_bytes": (_L, [_I, _I]),
+    "vc_op_fit_points": (_I, [_P, _P, C.POINTER(_F), C.POINTER(_F), _I, _I, _P, _P, _P, _P]),
+    "vc_op_fit_moments_scratch_bytes": (_L, []),
+    "vc_op_fit_moments": (_I, [_P, _L, _P, _P, _P]),
+    "vc_op_fit_project": (_I, [C.POINTER(_F), _P, _P, _P, _I, _I, _P]),
+    "vc_op_fit_blend": (_I, [_P, _P, _P, _F, C.POINTER(_F), _P, _P, _L, _P]),
+    "vc_op_fit_picture_u8": (_I, [_P, _P, _L, _P]),
     "vc_op_render_points_scratch_bytes": (_L, [_L, _I, _I, _I]),
     "vc_op_render_points": (_I, [_P, _P, _L, C.POINTER(_F), C.POINTER(_F), _I, _I, _F, _I, _F, _P, _P, _P, _P, _P]),
     "vc_op_render_mesh_scratch_bytes": (_L, [_I, _I, _I]),
