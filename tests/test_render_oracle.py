@@ -144,3 +144,32 @@ def test_mask_dilation_matches_an_elliptical_structuring_element():
     assert not d[10, 10] and not d[20, 20]                          # the corners of the 10 x 10 box are outside the ellipse
     pts = CM.depth_to_points(torch.full((4, 6), 2.0), torch.tensor([[3.0, 0, 2.5], [0, 4.0, 1.5], [0, 0, 1]]))
     assert torch.allclose(pts[1, 2], torch.tensor([(2 - 2.5) * 2 / 3, (1 - 1.5) * 2 / 4, 2.0]))
+
+
+@pytest.mark.parametrize("clip", ["street", "indoor"])
+def test_readers_on_the_reference_demo_files_and_the_step3_to_step5_convention(clip):
+    """The reference's REAL files (tests/golden/demo_fit/README.md): its Blender step exported `custom_camera_trajectory.npz` and
+    `custom_3D_gaussian_trajectory.json` from the `gaussian_params.json` its step 3 wrote.  The readers take them as they are, and in
+    frame 0 (objects at rest) the exported Gaussians ARE the fitted ones under COORD_TRANSFORM_CV2BLENDER - which
+    pins the world convention between the fit, the renderer and the trajectory files on reference data."""
+    d = os.path.join(os.path.dirname(__file__), "golden", "demo_fit", clip)
+    w2c = CM.load_camera_trajectory(os.path.join(d, "custom_camera_trajectory.npz"), device="cpu")
+    assert w2c.shape == (81, 4, 4) and w2c.dtype == torch.float32
+    # frame 0 is (all but a first step of) the camera of the input image: Blender world -> OpenCV camera = the inverse of CV2BLENDER
+    np.testing.assert_allclose(w2c[0, :3, :3].numpy(), CM.COORD_TRANSFORM_CV2BLENDER.T, atol=1e-5)
+    assert float(w2c[0, :3, 3].abs().max()) < 0.05
+    assert torch.allclose(w2c[:, :3, :3] @ w2c[:, :3, :3].transpose(1, 2), torch.eye(3).expand(81, 3, 3), atol=1e-5)
+    params, cidx, centers = CM.load_ellipsoid_parameters(os.path.join(d, "custom_3D_gaussian_trajectory_frames_0_1_40_80.json"), device="cpu")
+    fit = json.load(open(os.path.join(d, "gaussian_params.json")))
+    assert fit["obj_id_to_color_idx"].items() <= cidx.items() and len(params) == 4     # the indoor clip got a fourth object in Blender
+    T = CM.COORD_TRANSFORM_CV2BLENDER.astype(np.float64)
+    p0 = params[0]
+    for oid, g in fit["gaussian_params"].items():
+        mean, cov = p0[oid] if oid in p0 else p0[int(oid)]
+        np.testing.assert_allclose(mean.numpy(), T @ np.array(g["mean"]), atol=1e-5)
+        want = T @ np.array(g["cov"]) @ T.T
+        if clip == "indoor":                 # this clip's ellipsoids were re-shaped by hand in Blender (axis-aligned): the size survives
+            assert float(cov.trace()) == pytest.approx(np.trace(want), rel=1e-4)
+            assert float((cov - torch.diag(torch.diag(cov))).abs().max()) == 0.0
+        else:
+            np.testing.assert_allclose(cov.numpy(), want, atol=2e-5)
