@@ -371,6 +371,16 @@ int vc_op_fit_blend(const void* density, const void* mahal, const void* dmax, fl
                     int64_t npix, void* stream);
 int vc_op_fit_picture_u8(const void* src, void* dst, int64_t n, void* stream);
 
+/* ---- sample planes of the CLIs' .mp4 files (stands in for the ffmpeg call behind save_videos_grid, CLI.py:456, and
+ * save_video_from_frames, rendering_4D_control_maps.py:455-485).  The stream is H.264 with every macroblock I_PCM (ITU-T H.264 7.3.5);
+ * these entries convert uint8 RGB [F][H][W][3] <-> the macroblock layer [F][ceil(H/16) * ceil(W/16)][386] = {0x0D, 0x00, Y 16x16,
+ * Cb 8x8, Cr 8x8} in BT.601 limited range (integer forms in csrc/h264pcm.hip), edge pixels replicated into the cropped border.
+ * Headers and the MP4 boxes: versecrafter_amd/utils/mp4_pcm.py.  Device pointers.                                                  */
+const char* vc_h264_pcm_last_error(void);
+int64_t vc_op_h264_pcm_bytes(int frames, int H, int W);
+int vc_op_h264_pcm_pack(const void* rgb, void* out, int frames, int H, int W, void* stream);
+int vc_op_h264_pcm_unpack(const void* in, void* rgb, int frames, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

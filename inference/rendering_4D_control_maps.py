@@ -4,9 +4,9 @@ inference/rendering_4D_control_maps.py (:1146-1378) -- background_RGB, backgroun
 3D_gaussian_RGB (+ background_and_3D_gaussian) -- which are exactly what inference/versecrafter_inference.py reads as
 --rendering_maps_path.
 
-Every per-pixel stage runs on the HIP engine (versecrafter_amd/rendering/control_maps.py).  The image has no video codec: videos are
-written as .mp4 when a writer is importable, else as uint8 frame dumps `<name>.npy` ([F,H,W,3]) that the inference CLI reads directly
-(versecrafter_amd/utils/video_io.py)."""
+Every per-pixel stage runs on the HIP engine (versecrafter_amd/rendering/control_maps.py).  The image has no video codec library: videos are
+written by the package's own .mp4 writer (H.264 I_PCM, lossless in YCbCr 4:2:0; versecrafter_amd/utils/mp4_pcm.py), which the inference
+CLI reads back (versecrafter_amd/utils/video_io.py)."""
 import argparse
 import logging
 import os
@@ -50,22 +50,15 @@ def parse_args(argv=None):
 
 
 def save_video_from_frames(frames, output_path: Path, fps: int = 10):
-    """:455-485: a list of uint8 [H,W,3] (or [H,W]) frames -> video (or a frame dump when no writer is importable)."""
+    """:455-485: a list of uint8 [H,W,3] (or [H,W]) frames -> video.  No codec library in the image: the package's own .mp4 writer
+    (H.264 I_PCM, packed on the GPU; versecrafter_amd/utils/video_io.py), which the inference CLI of this repo reads back."""
     if len(frames) == 0:
         logger.warning(f"No frames to save for {output_path}")
         return None
     if frames[0].ndim == 2:
         frames = [f.unsqueeze(-1).repeat(1, 1, 3) for f in frames]
-    arr = torch.stack(list(frames)).cpu().numpy()
-    output_path.parent.mkdir(parents=True, exist_ok=True)
-    try:
-        import imageio
-        imageio.mimsave(str(output_path), list(arr), fps=fps)
-        return str(output_path)
-    except ImportError:
-        out = str(output_path.with_suffix(".npy"))
-        np.save(out, arr)
-        return out
+    from versecrafter_amd.utils.video_io import save_frames
+    return save_frames(torch.stack(list(frames)), str(output_path), fps)
 
 
 def main(argv=None):

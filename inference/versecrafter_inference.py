@@ -9,9 +9,9 @@ must equal N (the hybrid is run as pure Ulysses of that degree).
 A full run mirrors the reference's flow (CLI.py:187-465): DiT + GeoAdapter from --transformer_path, the Wan VAE and the umT5
 encoder from --model_name (or --vae_path / --text_encoder_path), the four control maps + merged mask + first frame from
 --rendering_maps_path / --input_image_path, the video written to --save_path.  All three models run on the HIP engine
-(versecrafter_amd.models).  The build image has no video codec: control maps are read from frame dumps next to the .mp4 files
-(or through any importable decoder) and the result is written as .mp4 only when a writer is importable, else as a uint8 frame
-dump -- see versecrafter_amd/utils/video_io.py.  --synthetic_inputs runs the denoising engine on random control latents /
+(versecrafter_amd.models).  The build image has no video codec library: control maps are read from frame dumps next to the .mp4 files,
+through any importable decoder, or -- the .mp4 files this repo's renderer CLI writes -- through the package's own H.264 I_PCM reader;
+the result is written as .mp4 the same way -- see versecrafter_amd/utils/video_io.py, utils/mp4_pcm.py.  --synthetic_inputs runs the denoising engine on random control latents /
 prompt embeddings of the right shapes (no VAE, no T5, latents saved as .safetensors).
 """
 import argparse

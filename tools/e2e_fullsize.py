@@ -58,7 +58,10 @@ def main():
         raise SystemExit(r.stderr[-3000:])
     for n in sorted(os.listdir(maps)):
         a = np.load(os.path.join(maps, n)) if n.endswith(".npy") else None
-        print(f"    {n}: {None if a is None else (a.shape, a.dtype, round(float(a.mean()), 2))}")
+        if n.endswith(".mp4"):                               # the package's own I_PCM writer
+            from versecrafter_amd.utils import mp4_pcm
+            a = mp4_pcm.read_mp4(os.path.join(maps, n)).cpu().numpy()
+        print(f"    {n}: {os.path.getsize(os.path.join(maps, n)) >> 20} MiB {None if a is None else (a.shape, a.dtype, round(float(a.mean()), 2))}")
 
     from oracle import vae_oracle as V                       # random weights of the published VAE architecture (names + shapes)
     cfg = V.Config(dim=96, z_dim=16)
@@ -83,6 +86,11 @@ def main():
             a = np.load(pth)
             print(f"    {n}: {a.shape} {a.dtype} mean {a.mean():.2f} std {a.std():.2f}")
             assert a.shape == (F_, H, W, 3) and a.dtype == np.uint8 and a.std() > 0
+        elif n.endswith(".mp4"):
+            from versecrafter_amd.utils import mp4_pcm
+            a = mp4_pcm.read_mp4(pth).cpu().numpy()
+            print(f"    {n}: {os.path.getsize(pth) >> 20} MiB, decodes to {a.shape} {a.dtype} mean {a.mean():.2f} std {a.std():.2f}")
+            assert a.shape == (F_, H, W, 3) and a.std() > 0
         else:
             print(f"    {n}: {os.path.getsize(pth)} bytes")
     print("e2e ok")

@@ -2,14 +2,17 @@
 (third-party, un-vendored; call sites inference/versecrafter_inference.py:370-403, 456 -- PARITY UNPINNED: decoder, resize
 filter and codec settings of those helpers are not in the reference tree).
 
-The build image has no video codec (no ffmpeg / cv2 / imageio / decord / av).  A control map is therefore looked up as
+The build image has no video codec library (no ffmpeg / cv2 / imageio / decord / av).  Writing: a codec library when one is
+importable, else the package's own .mp4 writer -- H.264 with every macroblock I_PCM, sample planes packed on the GPU
+(utils/mp4_pcm.py, csrc/h264pcm.hip): real, playable .mp4 files, lossless in YCbCr 4:2:0 -- and only without a GPU a uint8 frame dump
+(.npy).  Reading a control map:
   1. a frame dump next to the .mp4 -- `<name>.npy` (uint8 [F,H,W,3] or [F,H,W]), `<name>.npz` (key "frames") or
      `<name>.safetensors` (key "frames") -- which any machine with a decoder can produce once, then
-  2. the .mp4 itself through whichever decoder is importable (imageio, cv2, decord, av), else
-  3. an error that says so.
+  2. the .mp4 itself through whichever decoder is importable (imageio, cv2, decord, av), then
+  3. the .mp4 through the package's own reader when it is one of its own I_PCM files (what the renderer CLI of this repo writes), else
+  4. an error that says what the file is (the reference's demo clips are x264 High profile: they need a real decoder).
 Videos are returned as the reference's helpers return them: float32 [1, 3, F, H, W] in [0, 1], resized to `sample_size` (H, W)
-(bilinear), cut to `video_length` frames.  save_video writes .mp4 when imageio / cv2 is importable, else a uint8 frame dump
-(.npy) plus the first frame as .png (PIL is in the image)."""
+(bilinear), cut to `video_length` frames."""
 import os
 
 import numpy as np
@@ -70,8 +73,16 @@ def read_video(path, video_length, sample_size):
     if frames is None:
         if not os.path.isfile(path):
             raise FileNotFoundError(path)
-        raise RuntimeError(f"no video decoder is importable (imageio / cv2 / decord / av) and there is no frame dump "
-                           f"{stem}.npy|.npz|.safetensors for {path}: decode it once elsewhere (uint8 [F,H,W,3])")
+        why = "no GPU for the package's own I_PCM reader"
+        if torch.cuda.is_available():
+            from . import mp4_pcm
+            try:
+                frames = mp4_pcm.read_mp4(path, video_length).cpu().numpy()
+            except mp4_pcm.UnsupportedVideo as e:
+                why = str(e)
+        if frames is None:
+            raise RuntimeError(f"{path}: no video decoder is importable (imageio / cv2 / decord / av), there is no frame dump "
+                               f"{stem}.npy|.npz|.safetensors, and: {why}.  Decode it once elsewhere (uint8 [F,H,W,3])")
     frames = np.asarray(frames)[:video_length]
     if frames.ndim == 3:
         frames = np.repeat(frames[..., None], 3, axis=-1)
@@ -91,32 +102,45 @@ def read_image(path, sample_size):
     return a[None, :, None]
 
 
-def save_video(sample, path, fps=16):
-    """sample [B, 3, F, H, W] in [0, 1] (first item is written).  Returns the path actually written."""
-    frames = (sample[0].clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 3, 0).cpu().numpy()          # [F, H, W, 3]
+def save_frames(frames, path, fps=16):
+    """frames: uint8 [F, H, W, 3] (torch, any device) -> `path` (.mp4).  Returns the path actually written: a codec library's .mp4
+    when one is importable, else the package's own I_PCM .mp4 (GPU), else a frame dump `<stem>.npy` + the first frame as .png."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    if frames.shape[0] == 1:
-        from PIL import Image
-        out = os.path.splitext(path)[0] + ".png"
-        Image.fromarray(frames[0]).save(out)
-        return out
     try:
         import imageio
-        imageio.mimsave(path, list(frames), fps=fps)
+        imageio.mimsave(path, list(frames.cpu().numpy()), fps=fps)
         return path
     except ImportError:
         pass
     try:
         import cv2
-        w = cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"mp4v"), fps, (frames.shape[2], frames.shape[1]))
-        for f in frames:
+        host = frames.cpu().numpy()
+        w = cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"mp4v"), fps, (host.shape[2], host.shape[1]))
+        for f in host:
             w.write(cv2.cvtColor(f, cv2.COLOR_RGB2BGR))
         w.release()
         return path
     except ImportError:
         pass
+    F_, H, W = frames.shape[:3]
+    if torch.cuda.is_available() and H % 2 == 0 and W % 2 == 0:
+        from . import mp4_pcm
+        return mp4_pcm.write_mp4(path, frames if frames.is_cuda else frames.cuda(), fps=fps)
     out = os.path.splitext(path)[0] + ".npy"
-    np.save(out, frames)
+    host = frames.cpu().numpy()
+    np.save(out, host)
     from PIL import Image
-    Image.fromarray(frames[0]).save(os.path.splitext(path)[0] + "_frame0.png")
+    Image.fromarray(host[0]).save(os.path.splitext(path)[0] + "_frame0.png")
     return out
+
+
+def save_video(sample, path, fps=16):
+    """sample [B, 3, F, H, W] in [0, 1] (first item is written).  Returns the path actually written."""
+    frames = (sample[0].clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 3, 0).contiguous()          # [F, H, W, 3]
+    if frames.shape[0] == 1:
+        from PIL import Image
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        out = os.path.splitext(path)[0] + ".png"
+        Image.fromarray(frames[0].cpu().numpy()).save(out)
+        return out
+    return save_frames(frames, path, fps)
