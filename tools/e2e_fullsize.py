@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Whole flow at the bench clip's size on ONE MI355X, synthetic everything (no checkpoint is reachable offline):
   1. inference/rendering_4D_control_maps.py  -- synthetic scene (PNG + depth npz + object mask + 81-frame camera trajectory + ellipsoid
-     json, the file set of the reference's demo_data folders) -> the five control videos (frame dumps: the image has no codec)
+     json, the file set of the reference's demo_data folders) -> the five control videos (.mp4, the package's own I_PCM writer)
   2. inference/versecrafter_inference.py     -- Wan2.1-14B + GeoAdapter (random weights), production-width Wan VAE (random weights),
-     random prompt embeddings, N denoise steps, VAE decode -> generated_video_0 (frame dump)
+     random prompt embeddings, N denoise steps, VAE decode -> generated_video_0.mp4
    python tools/e2e_fullsize.py [workdir] [steps] [H] [W]"""
 import json
 import os
