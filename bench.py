@@ -29,7 +29,6 @@ fails too they exit non-zero with the tail of every rank's stderr file (bench_n<
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

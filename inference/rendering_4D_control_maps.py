@@ -16,7 +16,6 @@ from pathlib import Path
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import numpy as np
 import torch
 
 from versecrafter_amd.rendering import control_maps as R

@@ -9,7 +9,6 @@ import threading
 
 import pytest
 import torch
-from safetensors.torch import load_file
 
 from oracle import wan_oracle as O
 

@@ -61,7 +61,6 @@ def test_decode_matches_oracle(T, h, w):
 
 
 def test_errors_and_contract():
-    from versecrafter_amd import _lib
     cfg, Wf, m = make(TINY, 3)
     assert m.config.latent_channels == 16 and m.temporal_compression_ratio == 4 and m.spatial_compression_ratio == 8
     assert m.dtype == torch.bfloat16

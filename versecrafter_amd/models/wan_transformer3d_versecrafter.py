@@ -13,7 +13,7 @@ import json
 import math
 import os
 from types import SimpleNamespace
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Sequence
 
 import torch
 import torch.nn as nn

@@ -11,7 +11,7 @@ loop (T5 prompt encoding, VAE encode of the control maps, VAE decode) are used t
 """
 import math
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Union
+from typing import Callable, List, Optional
 
 import torch
 import torch.nn.functional as F
