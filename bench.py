@@ -273,6 +273,7 @@ def launch_ranks(args):
                            VC_BENCH_STATUS_DIR=status_dir, VC_BENCH_ATTEMPT=str(a))
                 # dmabuf IPC (versecrafter_amd.dist.ensure_ipc_env: the hosts of this pool refuse the legacy IPC mode)
                 env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                env.setdefault("NCCL_DEBUG", "WARN")                   # RCCL's own diagnostics into the per-rank stderr file (fd 1 is routed there)
                 if transport is not None:
                     env["VC_SP_TRANSPORT"] = transport
                 with open(err_paths[r], "a") as ef:
