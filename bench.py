@@ -441,6 +441,13 @@ def run_rank(args):
         for lay in layouts:                                            # process groups of every layout, created once
             groups[lay] = vdist.make_groups(lay[1], lay[0])
 
+    def ring_of(lay):
+        """--ring-degree R > 1 forces the Ulysses x ring hybrid; otherwise pure Ulysses wherever the head count divides by the group
+        and the smallest ring that fits where it does not (1.3B: 12 heads on 8 ranks -> 4 x 2), as the CLI chooses."""
+        if lay[1] <= 1:
+            return 1
+        return args.ring_degree if args.ring_degree > 1 else vdist.choose_ring_degree(lay[1], mk["num_heads"], 1)
+
     configured = [None]
 
     def configure(lay):
@@ -455,7 +462,7 @@ def run_rank(args):
             model.enable_multi_gpus_inference()                        # batch-parallel only: no sequence exchange
         else:
             if lay not in sps:
-                sps[lay] = vdist.SequenceParallel(sp_group, force_exchange=(world == 1), ring_degree=args.ring_degree if lay[1] > 1 else 1)
+                sps[lay] = vdist.SequenceParallel(sp_group, force_exchange=(world == 1), ring_degree=ring_of(lay))
             model.enable_multi_gpus_inference(sps[lay])
 
     # ---- bring-up, BEFORE any weight exists: every layout's communicators are created and each carries one probe collective;
@@ -569,7 +576,7 @@ def run_rank(args):
                 tr = "none (single rank)"
             out = {"value": sps_, "ms_per_step": 1000.0 * res["elapsed"] / args.steps,
                    "parallelism": (f"ulysses-sp{spd}" if cfgd == 1 else f"cfg{cfgd} x ulysses-sp{spd}") +
-                                  (f" (ulysses {spd // args.ring_degree} x ring {args.ring_degree})" if args.ring_degree > 1 and spd > 1 else ""),
+                                  (f" (ulysses {spd // ring_of(res['layout'])} x ring {ring_of(res['layout'])})" if ring_of(res["layout"]) > 1 else ""),
                    "cfg": "batched pair" if cfgd == 1 else "one sample per rank",
                    "step_mfma_frac": f_step * sps_ / (world * PEAK_BF16_TFLOPS * 1e12),
                    "outputs_finite": res["finite"],

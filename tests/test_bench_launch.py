@@ -211,3 +211,20 @@ def test_single_rank_rccl_exchange_path_through_bench():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["outputs_finite"] is True
+
+
+@pytest.mark.gpu
+def test_four_rank_rehearsals_on_one_gpu():
+    """--gpus 4 (the driver's next point after 2): `tiny` has 2 heads, so four ranks cannot be pure Ulysses -- the bench picks the
+    Ulysses 2 x ring 2 hybrid itself, as the CLI does for the 1.3B model on 8 GPUs; --cfg-degree 2 gives two Ulysses pairs."""
+    r = _run(["--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"], timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "ulysses-sp4 (ulysses 2 x ring 2)"
+    assert out["outputs_finite"] is True and out["rccl_observed"]["sp"]["ranks"] == 4 and out["rccl_observed"]["sp"]["ring_degree"] == 2
+    r = _run(["--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
+              "--cfg-degree", "2"], timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["config"]["parallelism"] == "cfg2 x ulysses-sp2" and out["outputs_finite"] is True
+    assert out["rccl_observed"] == {"sp": {"ranks": 2, "transport": "torch", "ring_degree": 1}, "cfg": {"ranks": 2, "backend": "gloo"}}
