@@ -263,3 +263,47 @@ def test_cfg_pair_across_ranks_equals_batched_pair_bitwise(world, sp_degree, tea
         assert err is None, (rank, err)
         assert ok, f"rank {rank}: max diff {diff}"
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _cli(tmp, nproc, extra, env_extra=None):
+    """inference/versecrafter_inference.py launched as the reference is (`torchrun --nproc-per-node=N ...`, inference.sh:62-71), several
+    ranks on this box's one GPU (VC_DIST_BACKEND=gloo: the rehearsal transport)."""
+    import socket
+    import subprocess
+    import sys
+    cli = os.path.join(ROOT, "inference", "versecrafter_inference.py")
+    common = ["--rendering_maps_path", "x", "--prompt", "a car drives", "--input_image_path", "x.png", "--num_inference_steps", "6",
+              "--sample_size", "64,96", "--video_length", "9", "--save_path", str(tmp), "--synthetic_inputs", "--synthetic_model", "tiny",
+              "--num_skip_start_steps", "2", "--output_latents", "1"] + extra
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    if nproc == 1:
+        cmd = [sys.executable, cli] + common
+    else:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        env["VC_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), cli] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from safetensors.torch import load_file
+    return load_file(os.path.join(str(tmp), "generated_latents_0.safetensors"))["latents"]
+
+
+def test_cli_under_torchrun_equals_the_single_rank_cli(tmp_path):
+    """The reference's launch shape for the CLI itself: 2 ranks as `--ulysses_degree 2`, 2 ranks as `--cfg_degree 2` (this build's
+    split of the CFG pair), and the 2-head model on 4 ranks as `--ulysses_degree 2 --ring_degree 2`.  Rank 0 writes the result; six
+    sampler steps with TeaCache on.  Ulysses and the CFG split re-partition the same arithmetic: final latents bit-equal to one rank;
+    the ring hybrid merges bf16 partial outputs: close."""
+    one = _cli(tmp_path / "p1", 1, ["--ulysses_degree", "1", "--ring_degree", "1"])
+    assert torch.isfinite(one.float()).all()
+    sp2 = _cli(tmp_path / "sp2", 2, ["--ulysses_degree", "2", "--ring_degree", "1"])
+    assert torch.equal(sp2, one)
+    cfg2 = _cli(tmp_path / "cfg2", 2, ["--ulysses_degree", "1", "--ring_degree", "1", "--cfg_degree", "2"])
+    assert torch.equal(cfg2, one)
+    hyb = _cli(tmp_path / "hyb", 4, ["--ulysses_degree", "2", "--ring_degree", "2"])
+    rel = float((hyb.float() - one.float()).norm() / one.float().norm())
+    assert rel < 3e-2, rel

@@ -49,7 +49,10 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
         if not dist.is_initialized():
             # host-side gloo for rendezvous / object broadcast (the ncclUniqueIds of the engine's communicators), torch's
             # "nccl" (= RCCL) registered for device tensors; the engine's exchanges never go through torch
-            dist.init_process_group("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
+            # VC_DIST_BACKEND=gloo: a launch rehearsal with several ranks on one device (RCCL refuses two ranks per GPU; gloo groups
+            # stage the exchange buffers through host memory, _host_bounce) -- tests only
+            dist.init_process_group(os.environ.get("VC_DIST_BACKEND") or
+                                    ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"))
         if dist.get_world_size() != world:
             raise ValueError(f"cfg_degree*ulysses_degree*ring_degree = {world} but world size is {dist.get_world_size()}")
         if int(ring_degree) > 1 and dist.get_rank() == 0:
@@ -58,6 +61,8 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
         make_groups(degree, cfg_degree)
     local = int(os.environ.get("LOCAL_RANK", 0))
     if torch.cuda.is_available():
+        if os.environ.get("VC_DIST_BACKEND") == "gloo":
+            local %= torch.cuda.device_count()                   # rehearsal: ranks share devices
         torch.cuda.set_device(local)
         return torch.device("cuda", local)
     return torch.device("cpu")
