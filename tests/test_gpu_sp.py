@@ -201,14 +201,16 @@ def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch)
 
 @pytest.mark.parametrize("P,ring,seq_len,cfg_pair,lanes", [
     (4, 2, 72, False, None), (2, 2, 72, False, None), (4, 2, 75, True, None), (4, 4, 72, False, "0"), (4, 2, 72, True, "2"),
-    (4, 2, 75, True, "3"), (2, 2, 75, False, "1"), (4, 2, 44, False, None)])
+    (4, 2, 75, True, "3"), (2, 2, 75, False, "1"), (4, 2, 44, False, None), (4, 2, 576, True, None), (4, 2, 510, False, "2"),
+    (4, 4, 1530, False, None)])
 def test_ulysses_x_ring_hybrid_matches_single_rank(P, ring, seq_len, cfg_pair, lanes, monkeypatch):
     """The Ulysses x ring hybrid (vc_sp_set_ring; the reference's --ulysses_degree U --ring_degree R) on P = U * R logical ranks:
     all-to-all inside each Ulysses group, K|V blocks round the ring, partial outputs merged by their log-sum-exps.  Not bit-equal to
     one rank (the partial outputs are rounded to bf16 and re-weighted; the ring kernel is the 16x16x32 form): the bound is the one of the
     engine against the oracle -- rel L2 < 1e-2 here, measured ~2e-3 -- on every rank, all ranks bit-equal to each other (the final
     all-gather), under every stream schedule; seq_len 75 -> 76 (masked tail inside the last block), seq_len 44 on 4 ranks x 2 -> whole
-    blocks... with U = 2, R = 2: block 1 holds tokens 22..43, all valid; and a clip whose LAST block is mostly padding."""
+    blocks... with U = 2, R = 2: block 1 holds tokens 22..43, all valid; and a clip whose LAST block is mostly padding; 576 / 510 / 1530
+    tokens: ring blocks of several 64-key tiles (the per-block key-length mask and the log-sum-exp merge across more than one tile)."""
     if lanes is not None:
         monkeypatch.setenv("VC_DUAL_LANE", lanes)
     cfg = O.Config(**TINY)
@@ -217,6 +219,12 @@ def test_ulysses_x_ring_hybrid_matches_single_rank(P, ring, seq_len, cfg_pair, l
     T, h, w = 3, 8, 12
     if seq_len == 44:
         T, h, w = 1, 8, 22                                   # 44 tokens
+    elif seq_len == 576:
+        T, h, w = 3, 24, 32                                  # ring blocks of 288 keys: 4.5 key tiles, the masked tail inside every block
+    elif seq_len == 510:
+        T, h, w = 3, 20, 34                                  # 510 tokens -> 512: blocks of 256 keys, the last one 254 valid
+    elif seq_len == 1530:
+        T, h, w = 3, 60, 34                                  # pure ring of 4: blocks of 383 keys (1532 padded), 6 tiles each
     x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
     geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
     if cfg_pair:
