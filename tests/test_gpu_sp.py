@@ -393,3 +393,60 @@ def test_rccl_init_rejects_bad_arguments():
     with pytest.raises(_lib.VcError):
         _lib.check(lib.vc_sp_init_rccl(hnd, 3, 0, ids, 2, 0), hnd)        # 3 does not divide 4 heads
     assert m.sp_comm_ranks() == 0
+
+
+@pytest.mark.parametrize("P,ring", [(4, 1), (8, 2)])
+def test_sp_at_the_1p3b_width_three_heads_per_rank(P, ring):
+    """Wan2.1-1.3B's width (d = 1536, 12 heads, ffn 8960, text 4096; depth cut to 4 + 2 blocks) at BASELINE config 1's clip (1920
+    tokens): 4 ranks of pure Ulysses hold 3 heads each (an odd head count per rank) -- bit-equal to one rank; 8 ranks cannot be pure
+    Ulysses (12 % 8), choose_ring_degree picks 4 x 2 -- the reference's own 8-GPU default shape (inference.sh:66-67) -- within the
+    hybrid's bound."""
+    from versecrafter_amd.dist import choose_ring_degree
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    assert choose_ring_degree(P, 12, 1) == ring
+    cfgk = dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=4, geoada_in_dim=128, in_dim=16, out_dim=16, text_dim=4096, text_len=512,
+                freq_dim=256)
+    W = O.random_weights(O.Config(**cfgk), 5)
+
+    def model():
+        m = VerseCrafterWanTransformer3DModel(**cfgk, skip_init=True)
+        m.load_state_dict(W)
+        return m.to(torch.bfloat16).to("cuda")
+    g = torch.Generator().manual_seed(4)
+    T, h, w = 3, 40, 64
+    x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    ctx = [torch.randn(60, 4096, generator=g).bfloat16().cuda(), torch.randn(77, 4096, generator=g).bfloat16().cuda()]
+    t = torch.tensor([640.0, 640.0]).cuda()
+    ref = model()(x, t, geo, ctx, 1920)
+    torch.cuda.synchronize()
+    comm = FakeComm(P)
+    models, sps = [], []
+    for r in range(P):
+        sp = FakeHybridSP(comm, r, ring) if ring > 1 else FakeSP(comm, r)
+        m = model()
+        m.enable_multi_gpus_inference(sp)
+        models.append(m)
+        sps.append(sp)
+    outs, errs = [None] * P, [None] * P
+
+    def run(r):
+        try:
+            outs[r] = models[r](x, t, geo, ctx, 1920)
+        except Exception as e:
+            errs[r] = e
+            comm.barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert errs[r] is None, (r, errs[r], sps[r].error)
+        assert torch.equal(outs[r], outs[0])
+    if ring == 1:
+        assert torch.equal(outs[0], ref)
+    else:
+        e = ((outs[0].float() - ref.float()).norm() / ref.float().norm()).item()
+        assert e < 1e-2, e
