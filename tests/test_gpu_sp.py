@@ -450,3 +450,59 @@ def test_sp_at_the_1p3b_width_three_heads_per_rank(P, ring):
     else:
         e = ((outs[0].float() - ref.float()).norm() / ref.float().norm()).item()
         assert e < 1e-2, e
+
+
+def test_sp8_at_the_14b_width_full_bench_sequence():
+    """BASELINE config 3's layout as the north star names it -- Ulysses over 8 ranks -- at the real per-rank shapes: d = 5120, 40 heads
+    (5 per rank), ffn 13824, text 512 x 4096, the bench clip's 32760 tokens (4095 per rank: not a multiple of any tile), CFG pair;
+    depth cut to 2 + 1 blocks so that eight logical ranks fit one GPU.  Every rank's output bit-equal to the single-rank forward."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dev = torch.device("cuda", 0)
+    dims = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=2, geoada_in_dim=128)
+
+    def model():
+        torch.manual_seed(0)                                 # identical random weights in every copy
+        m = VerseCrafterWanTransformer3DModel(param_device=dev, param_dtype=torch.bfloat16, skip_init=True, **dims)
+        m.init_weights(zero_init_outputs=False)
+        return m
+    g = torch.Generator().manual_seed(2025)
+    T, h, w = 21, 60, 104
+    x = torch.randn(1, 16, T, h, w, generator=g).to(dev, torch.bfloat16).expand(2, -1, -1, -1, -1).contiguous()
+    geo = torch.randn(1, 128, T, h, w, generator=g).to(dev, torch.bfloat16).expand(2, -1, -1, -1, -1).contiguous()
+    ctx = [torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16)]
+    t = torch.tensor([700.0, 700.0], device=dev)
+    L = 32760
+    one = model()
+    ref = one(x, t, geo, ctx, L).clone()
+    torch.cuda.synchronize()
+    del one
+    torch.cuda.empty_cache()
+    P = 8
+    comm = FakeComm(P)
+    models, sps = [], []
+    for r in range(P):
+        m = model()
+        sp = FakeSP(comm, r)
+        m.enable_multi_gpus_inference(sp)
+        models.append(m)
+        sps.append(sp)
+    outs, errs = [None] * P, [None] * P
+
+    def run(r):
+        try:
+            outs[r] = models[r](x, t, geo, ctx, L)
+        except Exception as e:
+            errs[r] = e
+            comm.barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert errs[r] is None, (r, errs[r], sps[r].error)
+        assert torch.isfinite(outs[r].float()).all()
+        assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
+    del models
+    torch.cuda.empty_cache()

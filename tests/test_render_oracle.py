@@ -173,3 +173,39 @@ def test_readers_on_the_reference_demo_files_and_the_step3_to_step5_convention(c
             assert float((cov - torch.diag(torch.diag(cov))).abs().max()) == 0.0
         else:
             np.testing.assert_allclose(cov.numpy(), want, atol=2e-5)
+
+
+def test_scripted_trajectory_files_have_the_reference_format(tmp_path):
+    """tools/make_trajectory.py (step 4 of inference.sh without Blender): at rest it reproduces frame 0 of the reference's own Blender
+    export for the street clip - same keys, same ids, means / covariances to float32 rounding - and the renderer's readers take its
+    files; a scripted motion moves camera and objects linearly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "tests", "golden", "demo_fit", "street")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "make_trajectory.py"), "--gaussian_json", os.path.join(d, "gaussian_params.json"),
+                        "--output_dir", str(tmp_path), "--num_frames", "5", "--dolly", "2.0", "--yaw_deg", "90", "--object_shift", "2:1,0,0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mine = json.load(open(tmp_path / "custom_3D_gaussian_trajectory.json"))
+    demo = json.load(open(os.path.join(d, "custom_3D_gaussian_trajectory_frames_0_1_40_80.json")))
+    assert mine["metadata"].keys() == demo["metadata"].keys() and mine["metadata"]["obj_id_to_color_idx"] == demo["metadata"]["obj_id_to_color_idx"]
+    assert mine["frames"][0].keys() == demo["frames"][0].keys()
+    for a, b in zip(mine["frames"][0]["objects"], demo["frames"][0]["objects"]):
+        assert a.keys() == b.keys() and a["object_id"] == b["object_id"] and a["gaussian_3d"].keys() == b["gaussian_3d"].keys()
+        np.testing.assert_allclose(a["gaussian_3d"]["mean"], b["gaussian_3d"]["mean"], atol=1e-6)
+        np.testing.assert_allclose(a["gaussian_3d"]["covariance"], b["gaussian_3d"]["covariance"], atol=1e-6)
+    params, cidx, centers = CM.load_ellipsoid_parameters(str(tmp_path / "custom_3D_gaussian_trajectory.json"), device="cpu")
+    assert len(params) == 5 and cidx == demo["metadata"]["obj_id_to_color_idx"]
+    key = "2" if "2" in params[0] else 2
+    np.testing.assert_allclose((params[4][key][0] - params[0][key][0]).numpy(), [1, 0, 0], atol=1e-6)       # object 2 drifted, the others rest
+    other = "1" if "1" in params[0] else 1
+    assert torch.equal(params[4][other][0], params[0][other][0])
+    w2c = CM.load_camera_trajectory(str(tmp_path / "custom_camera_trajectory.npz"), device="cpu")
+    demo_w2c = CM.load_camera_trajectory(os.path.join(d, "custom_camera_trajectory.npz"), device="cpu")
+    np.testing.assert_allclose(w2c[0].numpy(), np.vstack([np.hstack([CM.COORD_TRANSFORM_CV2BLENDER.T, np.zeros((3, 1))]), [[0, 0, 0, 1]]]), atol=1e-6)
+    np.testing.assert_allclose(w2c[0, :3, :3].numpy(), demo_w2c[0, :3, :3].numpy(), atol=1e-5)               # the demo's frame-0 orientation
+    # last frame: 2 units forward, turned 90 degrees to the left -> a world point 1 unit further ahead of the START pose (Blender +Y)
+    # sits ... at the camera's right-hand side?  No: the camera turned left, so what was ahead is now on its right: x_cam > 0.
+    p = w2c[4] @ torch.tensor([0.0, 3.0, 0.0, 1.0])
+    np.testing.assert_allclose(p[:3].numpy(), [1.0, 0.0, 0.0], atol=1e-5)
