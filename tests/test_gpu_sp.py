@@ -475,6 +475,7 @@ def test_sp8_at_the_14b_width_full_bench_sequence():
     one = model()
     ref = one(x, t, geo, ctx, L).clone()
     torch.cuda.synchronize()
+    assert ref.shape == (2, 16, T, h, w) and float(ref.float().abs().max()) > 0 and float(ref.float().std()) > 1e-3
     del one
     torch.cuda.empty_cache()
     P = 8
