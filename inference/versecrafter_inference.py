@@ -83,6 +83,13 @@ def parse_args(argv=None):
                    help="Wan2.1_VAE.pth / .safetensors (default: <model_name>/Wan2.1_VAE.pth, wan_civitai.yaml:9)")
     p.add_argument("--vae_kwargs", type=str, default="{}", help="JSON overrides of the VAE hyper-parameters (tests: {\"dim\": 32})")
     p.add_argument("--output_latents", type=int, default=0, help="1: also save the final latents as .safetensors")
+    p.add_argument("--transformer_high_noise_path", type=str, default=None,
+                   help="(this build; BASELINE config 5) checkpoint of the HIGH-noise expert of a Wan2.2-style pair "
+                        "(config/wan2.2/*.yaml: transformer_combination_type \"moe\"); --transformer_path is then the low-noise expert and "
+                        "steps with t >= --boundary * 1000 run the high-noise one.  Both experts stay resident in HBM")
+    p.add_argument("--boundary", type=float, default=0.875, help="config/wan2.2/wan_civitai_t2v.yaml: 0.875 (i2v: 0.900)")
+    p.add_argument("--synthetic_high_noise_expert", action="store_true",
+                   help="with --synthetic_model: a second random model (seed 1) as the high-noise expert")
     p.add_argument("--control_latents_path", type=str, default=None,
                    help=".safetensors with 'geoada_latents' [64,T,h,w] (VAE latents of the 4 control videos) and "
                         "'mask_video' [1,F,H,W] (merged mask): skips the VAE encode of the control maps")
@@ -108,6 +115,19 @@ def main(argv=None):
     else:
         transformer = VerseCrafterWanTransformer3DModel.from_pretrained(
             args.transformer_path,
+            transformer_additional_kwargs={"geoada_in_dim": args.geoada_in_dim,
+                                           "dict_mapping": {"in_dim": "in_channels", "dim": "hidden_size"}},
+            low_cpu_mem_usage=True, torch_dtype=weight_dtype).to(device)
+
+    transformer_2 = None
+    if args.synthetic_model and args.synthetic_high_noise_expert:
+        torch.manual_seed(1)
+        transformer_2 = VerseCrafterWanTransformer3DModel(geoada_in_dim=args.geoada_in_dim, param_device=device,
+                                                          param_dtype=weight_dtype, **dims)
+        transformer_2.init_weights(zero_init_outputs=False)
+    elif args.transformer_high_noise_path:
+        transformer_2 = VerseCrafterWanTransformer3DModel.from_pretrained(
+            args.transformer_high_noise_path,
             transformer_additional_kwargs={"geoada_in_dim": args.geoada_in_dim,
                                            "dict_mapping": {"in_dim": "in_channels", "dim": "hidden_size"}},
             low_cpu_mem_usage=True, torch_dtype=weight_dtype).to(device)
@@ -138,17 +158,20 @@ def main(argv=None):
 
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)  # CLI.py:252-261
     pipeline = WanVerseCrafterPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae,
-                                       transformer=transformer, scheduler=scheduler)
+                                       transformer=transformer, scheduler=scheduler, transformer_2=transformer_2)
+    experts = [m for m in (transformer, transformer_2) if m is not None]
     if args.ulysses_degree * args.ring_degree * args.cfg_degree > 1:
-        transformer.enable_multi_gpus_inference()                                   # CLI.py:271-273
+        for m in experts:
+            m.enable_multi_gpus_inference()                                         # CLI.py:271-273
     pipeline.to(device)
-    if args.enable_teacache:                                                        # CLI.py:305-313
-        transformer.enable_teacache(TEACACHE_COEFFICIENTS_14B, args.num_inference_steps, args.teacache_threshold,
-                                    num_skip_start_steps=args.num_skip_start_steps, offload=False)
-    if args.cfg_skip_ratio:
-        transformer.enable_cfg_skip(args.cfg_skip_ratio, args.num_inference_steps)
-    if args.enable_riflex:
-        transformer.enable_riflex(k=args.riflex_k, L_test=(args.video_length - 1) // 4 + 1)
+    for m in experts:
+        if args.enable_teacache:                                                    # CLI.py:305-313
+            m.enable_teacache(TEACACHE_COEFFICIENTS_14B, args.num_inference_steps, args.teacache_threshold,
+                              num_skip_start_steps=args.num_skip_start_steps, offload=False)
+        if args.cfg_skip_ratio:
+            m.enable_cfg_skip(args.cfg_skip_ratio, args.num_inference_steps)
+        if args.enable_riflex:
+            m.enable_riflex(k=args.riflex_k, L_test=(args.video_length - 1) // 4 + 1)
 
     generator = torch.Generator(device=device).manual_seed(args.seed)               # CLI.py:319
     T, h, w = (args.video_length - 1) // 4 + 1, height // 8, width // 8
@@ -206,7 +229,7 @@ def main(argv=None):
     sample = pipeline(height=height, width=width, num_frames=args.video_length, generator=generator,
                       guidance_scale=args.guidance_scale, num_inference_steps=args.num_inference_steps,
                       shift=args.shift, geoada_context_scale=args.geoada_context_scale,
-                      output_type="numpy" if decode else "latent", callback_on_step_end=keep_latents,
+                      output_type="numpy" if decode else "latent", callback_on_step_end=keep_latents, boundary=args.boundary,
                       **control, **embeds).videos
     torch.cuda.synchronize()
     dt = time.time() - t0

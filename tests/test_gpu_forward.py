@@ -347,6 +347,12 @@ def test_cli_runs_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = load_file(os.path.join(str(tmp_path), "generated_latents_0.safetensors"))["latents"]
     assert out.shape == (1, 16, 3, 8, 12) and torch.isfinite(out).all()
+    # the Wan2.2-style expert pair through the CLI (this build's flags): a second random model runs the high-noise steps
+    r = subprocess.run(cmd + ["--synthetic_high_noise_expert", "--boundary", "0.9", "--shift", "12", "--save_path", str(tmp_path / "moe")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = load_file(os.path.join(str(tmp_path / "moe"), "generated_latents_0.safetensors"))["latents"]
+    assert two.shape == out.shape and torch.isfinite(two).all() and not torch.equal(two, out)
 
 
 @pytest.mark.parametrize("name,dims,grid", [
@@ -484,6 +490,47 @@ def wan14b():
     m.init_weights(zero_init_outputs=False)
     yield m
     del m
+    torch.cuda.empty_cache()
+
+
+def test_two_resident_14b_experts_switch_at_the_boundary(wan14b):
+    """BASELINE config 5's model pair at full size: two Wan-14B + GeoAdapter experts (2 x 43.7 GB of weights) resident on ONE MI355X,
+    a four-step sampler that crosses the boundary; the result equals the single-expert pipelines swapped by hand at the switch."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    high = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16,
+                                             dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, skip_init=True)
+    high.init_weights(zero_init_outputs=False)
+    g = torch.Generator().manual_seed(9)
+    T, h, w = 2, 16, 24
+    lat0 = torch.randn(1, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    geo = torch.randn(64, T, h, w, generator=g).to(dev, torch.bfloat16)
+    msk = (torch.rand(64, T, h, w, generator=g) < 0.5).to(dev, torch.bfloat16)
+    pe, ne = torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16)
+
+    def run(t1, t2=None, callback=None):
+        pipe = WanVerseCrafterPipeline(transformer=t1, transformer_2=t2, scheduler=FlowUniPCMultistepScheduler(shift=1))
+        out = pipe(prompt_embeds=[pe], negative_prompt_embeds=[ne], height=h * 8, width=w * 8, geoada_latents=[geo], mask_latents=[msk],
+                   num_inference_steps=4, guidance_scale=5.0, shift=12, latents=lat0.clone(), output_type="latent", boundary=0.875,
+                   callback_on_step_end=callback).videos
+        torch.cuda.synchronize()
+        return out, pipe
+    mixed, pipe = run(wan14b, high)
+    hi = pipe._high_noise_steps
+    assert 0 < sum(hi) < 4 and torch.isfinite(mixed.float()).all()
+
+    def swap(p, i, t, kw):
+        p.transformer = high if (i + 1 < 4 and hi[i + 1]) else wan14b
+        return kw
+    want, _ = run(high if hi[0] else wan14b, callback=swap)
+    assert torch.equal(mixed, want)
+    free, total = torch.cuda.mem_get_info()
+    print(f"two resident 14B experts: {(total - free) / 2**30:.1f} GiB of {total / 2**30:.0f} GiB in use")
+    assert total - free > 80 * 2**30                          # both sets of weights are on the device
+    del high
     torch.cuda.empty_cache()
 
 
@@ -642,3 +689,52 @@ def test_graph_replay_equals_eager_bitwise(fwd, monkeypatch):
     for i in range(5):                               # calc, calc, skip, skip, skip: STORE graphs, then USE graphs
         assert torch.equal(run(graph, fwd, L, x=xs[i], t=ts[i]), run(eager, fwd, L, x=xs[i], t=ts[i])), i
         assert graph.should_calc == eager.should_calc == (i < 2)
+
+
+def test_two_expert_sampler_switches_at_the_boundary(model):
+    """BASELINE config 5's "MoE" as upstream Wan2.2 defines it (two full DiTs switched by the timestep; the reference ships only the
+    configs): steps with t >= boundary * 1000 run transformer_2.  Checked against single-model runs: boundary above every timestep =
+    the low-noise model alone, boundary 0 = the high-noise model alone, a boundary in between = a single-model pipeline whose model is
+    swapped by a step callback at the switch -- all bit-equal; both experts carry their own TeaCache state."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.pipeline.pipeline_wan_versecrafter import expert_schedule
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    cfg = O.Config(**TINY)
+    low = model
+    high = VerseCrafterWanTransformer3DModel(**TINY)
+    high.load_state_dict(O.random_weights(cfg, 23))
+    high = high.to(torch.bfloat16).to("cuda")
+    g = torch.Generator().manual_seed(5)
+    T, h, w = 3, 8, 12
+    lat0 = torch.randn(1, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(64, T, h, w, generator=g).bfloat16().cuda()
+    msk = (torch.rand(64, T, h, w, generator=g) < 0.5).to(torch.bfloat16).cuda()
+    pe, ne = torch.randn(33, cfg.text_dim, generator=g).bfloat16().cuda(), torch.randn(20, cfg.text_dim, generator=g).bfloat16().cuda()
+    steps = 6
+
+    def run(t1, t2=None, boundary=0.875, callback=None):
+        pipe = WanVerseCrafterPipeline(transformer=t1, transformer_2=t2, scheduler=FlowUniPCMultistepScheduler(shift=1))
+        out = pipe(prompt_embeds=[pe], negative_prompt_embeds=[ne], height=h * 8, width=w * 8, geoada_latents=[geo], mask_latents=[msk],
+                   num_inference_steps=steps, guidance_scale=5.0, shift=12, latents=lat0.clone(), output_type="latent", boundary=boundary,
+                   callback_on_step_end=callback).videos
+        torch.cuda.synchronize()
+        return out, pipe
+    only_low, _ = run(low)
+    only_high, _ = run(high)
+    assert not torch.equal(only_low, only_high)
+    a, _ = run(low, high, boundary=1.1)
+    assert torch.equal(a, only_low)
+    b, _ = run(low, high, boundary=0.0)
+    assert torch.equal(b, only_high)
+    mixed, pipe = run(low, high, boundary=0.875)
+    hi = pipe._high_noise_steps
+    assert hi == expert_schedule(pipe.scheduler.timesteps, 0.875) and 0 < sum(hi) < steps          # shift 12: the first steps are above 875
+
+    def swap(p, i, t, kw):
+        p.transformer = high if (i + 1 < steps and hi[i + 1]) else low
+        return kw
+    want, _ = run(high if hi[0] else low, callback=swap)
+    assert torch.equal(mixed, want)
+    assert torch.isfinite(mixed.float()).all() and not torch.equal(mixed, only_low) and not torch.equal(mixed, only_high)
+

@@ -236,3 +236,20 @@ def test_video_io_frame_dumps_roundtrip(tmp_path):
     assert os.path.isfile(out)
     if out.endswith(".npy"):
         assert np.array_equal(np.load(out), frames[:5])
+
+
+def test_expert_schedule_of_a_two_expert_pair():
+    """BASELINE config 5 (config/wan2.2: transformer_combination_type "moe", boundary 0.875 / 0.900): which sampler steps run the
+    high-noise expert -- t >= boundary * num_train_timesteps, decided once per call from the scheduler's own timesteps."""
+    from versecrafter_amd.pipeline.pipeline_wan_versecrafter import expert_schedule
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    assert expert_schedule(torch.tensor([999.0, 875.0, 874.99, 10.0]), 0.875) == [True, True, False, False]
+    assert expert_schedule([500, 400], 0.45, 1000) == [True, False]
+    sch = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    sch.set_timesteps(50, device="cpu", shift=12.0)                     # the yaml's shift
+    hi = expert_schedule(sch.timesteps, 0.875, sch.config.num_train_timesteps)
+    assert hi[0] and not hi[-1] and hi == sorted(hi, reverse=True)      # one switch, high noise first
+    t = sch.timesteps.float()
+    assert sum(hi) == int((t >= 875).sum()) and 0 < sum(hi) < 50
+    assert not any(expert_schedule(sch.timesteps, 1.1)) and all(expert_schedule(sch.timesteps, 0.0))
+

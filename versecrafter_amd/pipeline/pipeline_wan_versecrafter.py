@@ -49,10 +49,24 @@ def geoada_latent(z, m):
     return [torch.cat([zz, mm], dim=0) for zz, mm in zip(z, m)]
 
 
+def expert_schedule(timesteps, boundary: float, num_train_timesteps: int = 1000):
+    """Which expert runs each sampler step of a Wan2.2-style pair: True -> the high-noise expert (t >= boundary *
+    num_train_timesteps).  One host read of the schedule per call; the loop itself stays free of device read-backs."""
+    thr = float(boundary) * float(num_train_timesteps)
+    return [bool(v >= thr) for v in torch.as_tensor(timesteps).detach().float().cpu().tolist()]
+
+
 class WanVerseCrafterPipeline:
-    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None):
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None, transformer_2=None):
+        """transformer_2 (this build; BASELINE config 5): the HIGH-noise expert of a Wan2.2-style pair -- the reference ships the
+        configs (config/wan2.2/*.yaml: transformer_combination_type "moe", low / high noise sub-paths, `boundary`) but no code that
+        reads them.  Upstream's "MoE" is two full DiTs switched by the timestep, not token routing: steps with t >= boundary *
+        num_train_timesteps run transformer_2, the rest `transformer` (the low-noise expert).  Both stay resident in HBM (2 x 43.7 GB
+        for 14B + GeoAdapter), each with its own per-video state; there is no exchange between them."""
         self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
         self.transformer, self.scheduler = transformer, scheduler
+        self.transformer_2 = transformer_2
+        self._high_noise_steps = None   # per sampler step: True -> transformer_2 (decided on the host once per call)
         self._guidance_scale = 1.0
         self._interrupt = False
         self._device = None
@@ -61,7 +75,7 @@ class WanVerseCrafterPipeline:
     # -- small parts of the DiffusionPipeline surface the CLI touches ---------------------------------
     def to(self, device):
         self._device = torch.device(device)
-        for m in (self.transformer, self.vae, self.text_encoder):
+        for m in (self.transformer, self.transformer_2, self.vae, self.text_encoder):
             if m is not None and hasattr(m, "to"):
                 m.to(device)
         return self
@@ -137,17 +151,20 @@ class WanVerseCrafterPipeline:
     def denoise_step(self, i, t, latents, in_prompt_embeds, geoada_context_input, seq_len, do_cfg,
                      geoada_context_scale=1.0):
         """One iteration of PIPE.py:871-925."""
-        self.transformer.current_steps = i
+        model = self.transformer
+        if self.transformer_2 is not None and self._high_noise_steps is not None and self._high_noise_steps[i]:
+            model = self.transformer_2
+        model.current_steps = i
         latent_model_input = torch.cat([latents] * 2) if do_cfg else latents
         if hasattr(self.scheduler, "scale_model_input"):
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
         timestep = t.expand(latent_model_input.shape[0])
         if do_cfg and latents.shape[0] == 1 and self._cfg_pair_maps is geoada_context_input and \
-                hasattr(self.transformer, "assert_cfg_pair"):
-            self.transformer.assert_cfg_pair(latent_model_input)    # [u, u] built right here and in __call__: no device check
-        noise_pred = self.transformer(x=latent_model_input, context=in_prompt_embeds, t=timestep,
-                                      geoada_context=geoada_context_input, seq_len=seq_len,
-                                      geoada_context_scale=geoada_context_scale)
+                hasattr(model, "assert_cfg_pair"):
+            model.assert_cfg_pair(latent_model_input)               # [u, u] built right here and in __call__: no device check
+        noise_pred = model(x=latent_model_input, context=in_prompt_embeds, t=timestep,
+                           geoada_context=geoada_context_input, seq_len=seq_len,
+                           geoada_context_scale=geoada_context_scale)
         if (hasattr(self.scheduler, "step_cfg") and latents.is_cuda and latents.dtype == torch.bfloat16 and
                 noise_pred.dtype == torch.bfloat16 and (not do_cfg or noise_pred.shape[0] == 2 * latents.shape[0])):
             # CFG combine + x0 + UniPC corrector / predictor in one HIP kernel; bit-identical to the two steps below
@@ -166,9 +183,10 @@ class WanVerseCrafterPipeline:
                  callback_on_step_end: Optional[Callable] = None, attention_kwargs=None,
                  callback_on_step_end_tensor_inputs=("latents",), max_sequence_length: int = 512,
                  comfyui_progressbar: bool = False, shift: int = 5, geoada_context_scale: float = 1.0,
-                 geoada_latents=None, mask_latents=None):
+                 geoada_latents=None, mask_latents=None, boundary: float = 0.875):
         """PIPE.py:652-948.  Extensions (keyword-only in practice): `geoada_latents` (list of [64,T,h,w] control
-        latents, replacing the VAE encode) and `mask_latents` (list of [64,T,h,w])."""
+        latents, replacing the VAE encode), `mask_latents` (list of [64,T,h,w]) and `boundary` (with a transformer_2: the fraction
+        of num_train_timesteps at and above which the high-noise expert runs; config/wan2.2/wan_civitai_t2v.yaml: 0.875)."""
         if subject_ref_images is not None:
             raise NotImplementedError("subject_ref_images is not used by the VerseCrafter CLI (CLI.py:431)")
         num_videos_per_prompt = 1                                                   # PIPE.py:696
@@ -217,6 +235,10 @@ class WanVerseCrafterPipeline:
                                        device, generator, latents)
         seq_len = math.ceil((h * w) / (self.transformer.config.patch_size[1] * self.transformer.config.patch_size[2]) * T)
         self.transformer.num_inference_steps = num_inference_steps                  # PIPE.py:869
+        self._high_noise_steps = None
+        if self.transformer_2 is not None:
+            self.transformer_2.num_inference_steps = num_inference_steps
+            self._high_noise_steps = expert_schedule(timesteps, boundary, self.scheduler.config.num_train_timesteps)
         # the reference re-stacks this every step (PIPE.py:883-887); it is step-invariant
         geoada_context_input = torch.stack(geoada_context * 2) if do_cfg else torch.stack(geoada_context)
         self._cfg_pair_maps = geoada_context_input if (do_cfg and len(geoada_context) == 1) else None
