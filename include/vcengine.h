@@ -381,6 +381,23 @@ int64_t vc_op_h264_pcm_bytes(int frames, int H, int W);
 int vc_op_h264_pcm_pack(const void* rgb, void* out, int frames, int H, int W, void* stream);
 int vc_op_h264_pcm_unpack(const void* in, void* rgb, int frames, int H, int W, void* stream);
 
+/* ---- fp8 GEMM operands (BASELINE config 5 names "fp8 MFMA"; a capability of this build, off by default: the reference computes in bf16
+ * and its fp8 mode only STORES weights in fp8, CLI.py:292-301).  OCP e4m3, one fp32 scale per row: x ~ q * scale, scale = amax / 448.
+ *   vc_op_quantize_rows_fp8   bf16 [M, K] (ldx elements) -> uint8 e4m3 [M, K] (ldq bytes) + float32 scale [M]
+ *   vc_op_gemm_fp8            C bf16 [M, N] = epilogue((A W^T) a_scale[m] w_scale[n]); A [M, K], W [N, K] e4m3; epilogue kinds BIAS,
+ *                             BIAS_GELU, BIAS_RESID, BIAS_GATE_RESID as vc_op_gemm_bf16.  N % 256 == 0, K % 256 == 0, M % 256 == 0 unless
+ *                             a_rows_padded (rows of A up to the next multiple of 256 readable), 16-byte aligned operands.        */
+/*   vc_set_fp8_linear         engine mode: on != 0 gives every nn.Linear of the main and adapter blocks (self-attention q/k/v/o, cross-attention
+ *                             q/o, ffn.0/ffn.2, before_proj/after_proj) an e4m3 copy with per-output-channel scales (all weights must be
+ *                             loaded); their GEMMs then quantise the activations per token and run in fp8.  Attention, norms, embeddings,
+ *                             text K/V and the head stay bf16.  on == 0 frees the copies.  vc_fp8_linear: 1 when the mode is on.        */
+int vc_set_fp8_linear(vc_engine* h, int on);
+int vc_fp8_linear(const vc_engine* h);
+int vc_op_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* scale, int M, int K, void* stream);
+int vc_op_gemm_fp8(const void* A, int64_t lda, const void* a_scale, const void* W, int64_t ldw, const void* w_scale, void* C, int64_t ldc,
+                   const void* bias, int M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate,
+                   int64_t gate_bstride, int rows_per_batch, int a_rows_padded, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,10 @@ def parse_args(argv=None):
                         "(config/wan2.2/*.yaml: transformer_combination_type \"moe\"); --transformer_path is then the low-noise expert and "
                         "steps with t >= --boundary * 1000 run the high-noise one.  Both experts stay resident in HBM")
     p.add_argument("--boundary", type=float, default=0.875, help="config/wan2.2/wan_civitai_t2v.yaml: 0.875 (i2v: 0.900)")
+    p.add_argument("--fp8_linear", type=int, default=0,
+                   help="(this build; BASELINE config 5 names fp8 MFMA) 1: the blocks' nn.Linear layers run in fp8 (e4m3 weights per output "
+                        "channel, activations per token, fp32 accumulation); attention and everything else stay bf16.  The reference "
+                        "computes in bf16: results then differ from it by the quantisation error")
     p.add_argument("--synthetic_high_noise_expert", action="store_true",
                    help="with --synthetic_model: a second random model (seed 1) as the high-noise expert")
     p.add_argument("--control_latents_path", type=str, default=None,
@@ -165,6 +169,8 @@ def main(argv=None):
             m.enable_multi_gpus_inference()                                         # CLI.py:271-273
     pipeline.to(device)
     for m in experts:
+        if args.fp8_linear:
+            m.enable_fp8_linear()
         if args.enable_teacache:                                                    # CLI.py:305-313
             m.enable_teacache(TEACACHE_COEFFICIENTS_14B, args.num_inference_steps, args.teacache_threshold,
                               num_skip_start_steps=args.num_skip_start_steps, offload=False)

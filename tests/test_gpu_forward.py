@@ -738,3 +738,57 @@ def test_two_expert_sampler_switches_at_the_boundary(model):
     assert torch.equal(mixed, want)
     assert torch.isfinite(mixed.float()).all() and not torch.equal(mixed, only_low) and not torch.equal(mixed, only_high)
 
+
+def test_fp8_linear_mode(model):
+    """enable_fp8_linear (this build; BASELINE config 5's dtype): the blocks' Linear layers on e4m3 operands.  The output moves away
+    from the bf16 forward by the quantisation error and no further (tiny model: < 8e-2 rel L2), is deterministic, survives re-loading
+    the weights, and switching the mode off restores the bf16 forward bit for bit."""
+    g = torch.Generator().manual_seed(21)
+    T, h, w = 3, 8, 12
+    x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+    t = torch.tensor([640.0, 640.0]).cuda()
+    ref = model(x, t, geo, ctx, 72).clone()
+    model.enable_fp8_linear()
+    try:
+        a = model(x, t, geo, ctx, 72).clone()
+        b = model(x, t, geo, ctx, 72).clone()
+        assert torch.equal(a, b) and torch.isfinite(a.float()).all()
+        e = rel(a, ref)
+        assert 1e-4 < e < 8e-2, e
+        model.mark_weights_changed()                               # parameters re-registered: the e4m3 copies are rebuilt
+        for p_ in model.parameters():
+            p_._version                                            # (no change of values)
+        c = model(x, t, geo, ctx, 72)
+        assert torch.equal(c, a)
+    finally:
+        model.enable_fp8_linear(False)
+    assert torch.equal(model(x, t, geo, ctx, 72), ref)
+
+
+def test_fp8_linear_at_the_14b_width_against_bf16():
+    """The same at the production width (d = 5120, 40 heads, ffn 13824; 2 + 1 blocks, 768 tokens): every fp8 GEMM shape of the real
+    model, against the bf16 engine."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = VerseCrafterWanTransformer3DModel(param_device=dev, param_dtype=torch.bfloat16, skip_init=True, geoada_in_dim=128, dim=5120,
+                                          ffn_dim=13824, num_heads=40, num_layers=2)
+    m.init_weights(zero_init_outputs=False)
+    g = torch.Generator().manual_seed(2)
+    T, h, w = 2, 16, 48
+    x = torch.randn(2, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    geo = torch.randn(2, 128, T, h, w, generator=g).to(dev, torch.bfloat16)
+    ctx = [torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16)]
+    t = torch.tensor([700.0, 700.0], device=dev)
+    L = T * (h // 2) * (w // 2)
+    ref = m(x, t, geo, ctx, L).clone()
+    m.enable_fp8_linear()
+    got = m(x, t, geo, ctx, L).clone()
+    e = rel(got, ref)
+    print(f"14B width, fp8 linear layers vs bf16: rel L2 {e:.4g}")
+    assert torch.isfinite(got.float()).all() and 1e-4 < e < 8e-2, e
+    del m
+    torch.cuda.empty_cache()
+

@@ -518,3 +518,76 @@ def test_config4_sequence_length_attention():
     perm = torch.randperm(L, device="cuda", generator=g)
     o3 = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous())
     assert rel_l2(o3, o1.float().cpu()) < 4e-3
+
+
+def _deq(q, sc):
+    return q.view(torch.float8_e4m3fn).float() * sc[:, None]
+
+
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 512), (1024, 5120), (77, 13824)])
+def test_fp8_row_quantiser_equals_torch_cast(ops, M, K):
+    """vc_op_quantize_rows_fp8: scale = amax / 448 per row, bytes = torch's own round-to-nearest-even cast to OCP e4m3 of x / scale."""
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).bfloat16().cuda()
+    x[M // 2] = 0                                                   # an all-zero row: scale 1, bytes 0
+    q, sc = ops.quantize_rows_fp8(x)
+    want_sc = x.float().abs().amax(1) / 448.0
+    want_sc[M // 2] = 1.0
+    assert torch.equal(sc, want_sc)
+    want_q = (x.float() * (1.0 / want_sc)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q, want_q)
+    err = ((_deq(q, sc) - x.float()).norm() / x.float().norm()).item()
+    assert err < 4e-2                                               # 3 mantissa bits
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, "bias"), (512, 768, 1024, "gelu"), (1000, 512, 512, "resid"), (2048, 5120, 5120, "gate"),
+                                        (4095, 1536, 8960, "bias")])
+def test_gemm_fp8_against_the_dequantised_product(ops, M, N, K, epi):
+    """vc_op_gemm_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation) = epilogue((A_q W_q^T) a_scale w_scale + bias) computed in
+    fp32 from the SAME e4m3 operands; what remains is the bf16 rounding of the output and of the epilogue's intermediate steps.  Rows
+    past M up to the next multiple of 256 are readable padding (the engine's arena rule)."""
+    from versecrafter_amd import ops as OPS
+    g = torch.Generator().manual_seed(M + N + K)
+    Mp = (M + 255) // 256 * 256
+    a = torch.zeros(Mp, K, dtype=torch.bfloat16)
+    a[:M] = torch.randn(M, K, generator=g).bfloat16()
+    a = a.cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).bfloat16().cuda()
+    aq, asc = ops.quantize_rows_fp8(a)
+    wq, wsc = ops.quantize_rows_fp8(w)
+    prod = _deq(aq[:M], asc[:M]) @ _deq(wq, wsc).T + bias.float()
+    rb = lambda t: t.bfloat16().float()
+    kw = {}
+    if epi == "bias":
+        want, code = prod, OPS.EPI_BIAS
+    elif epi == "gelu":
+        want, code = torch.nn.functional.gelu(rb(prod), approximate="tanh"), OPS.EPI_BIAS_GELU
+    elif epi == "resid":
+        r = torch.randn(M, N, generator=g).bfloat16().cuda()
+        want, code, kw = r.float() + rb(prod), OPS.EPI_BIAS_RESID, dict(resid=r)
+    else:
+        r = torch.randn(M, N, generator=g).bfloat16().cuda()
+        gate = torch.randn(2, N, generator=g).bfloat16().cuda()
+        rows = M // 2
+        gsel = gate.float()[torch.arange(M, device="cuda") // rows]
+        want, code, kw = r.float() + rb(rb(prod) * gsel), OPS.EPI_BIAS_GATE_RESID, dict(resid=r, gate=gate, rows_per_batch=rows)
+    got = ops.gemm_fp8(aq[:M], asc[:M], wq, wsc, bias=bias, epilogue=code, a_rows_padded=True, **kw).float()
+    torch.cuda.synchronize()
+    e = ((got - want).norm() / want.norm()).item()
+    assert e < 4e-3, e
+    full = a[:M].float() @ w.float().T + bias.float()
+    assert ((prod - full).norm() / full.norm()).item() < 5e-2      # what the quantisation itself costs against the bf16 operands
+
+
+def test_gemm_fp8_rejects_what_the_kernel_does_not_take(ops):
+    from versecrafter_amd import _lib
+    a = torch.zeros(256, 256, dtype=torch.uint8, device="cuda")
+    s = torch.ones(256, device="cuda")
+    with pytest.raises(_lib.VcError):
+        ops.gemm_fp8(a, s, torch.zeros(128, 256, dtype=torch.uint8, device="cuda"), torch.ones(128, device="cuda"))     # N % 256
+    with pytest.raises(_lib.VcError):
+        ops.gemm_fp8(torch.zeros(256, 128, dtype=torch.uint8, device="cuda"), s, torch.zeros(256, 128, dtype=torch.uint8, device="cuda"), s)  # K % 256
+    with pytest.raises(_lib.VcError):
+        ops.gemm_fp8(a[:100], s[:100], a, s)                                                                             # M % 256 without padding
+

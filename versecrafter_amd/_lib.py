@@ -91,6 +91,10 @@ SYMBOLS = {
     "vc_op_render_gauss_density": (_I, [_P, _I, _P, _I, _I, _P]),
     "vc_op_render_gauss_frame": (_I, [_P, _I, _P, _F, _F, _P, _P, _I, _I, _P]),
     "vc_op_render_blend": (_I, [_P, _P, _P, _P, _L, _I, _P]),
+    "vc_set_fp8_linear": (_I, [_P, _I]),
+    "vc_fp8_linear": (_I, [_P]),
+    "vc_op_quantize_rows_fp8": (_I, [_P, _L, _P, _L, _P, _I, _I, _P]),
+    "vc_op_gemm_fp8": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _I, _P]),
     "vc_h264_pcm_last_error": (C.c_char_p, []),
     "vc_op_h264_pcm_bytes": (_L, [_I, _I, _I]),
     "vc_op_h264_pcm_pack": (_I, [_P, _P, _I, _I, _I, _P]),

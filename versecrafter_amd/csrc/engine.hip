@@ -120,6 +120,16 @@ struct vc_engine {
     vc_sendrecv_fn sendrecv = nullptr;
     hipEvent_t ev_ring[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
+    // fp8 linear layers (vc_set_fp8_linear; BASELINE config 5's dtype, off by default): e4m3 copies + per-output-channel scales of
+    // the blocks' nn.Linear weights, keyed by the bf16 weight pointer; activations are quantised per token in front of every such GEMM
+    // into a per-stream scratch (rows padded to the GEMM's 256-row tiles).
+    struct Fp8W { void* q = nullptr; float* scale = nullptr; };
+    struct Fp8Scratch { void* q = nullptr; float* scale = nullptr; int64_t rows = 0, cols = 0; };
+    bool fp8 = false;               // the copies exist
+    bool fp8_want = false;          // the mode is on (copies are rebuilt by vc_prepare_video after a weight was re-loaded)
+    std::unordered_map<const void*, Fp8W> fp8w;
+    std::unordered_map<hipStream_t, Fp8Scratch> fp8a;
+
     // prepared video
     bool prepared = false;
     int B = 0, T = 0, H = 0, W = 0, H2 = 0, W2 = 0, L = 0, Lpad = 0, Lloc = 0, M = 0, tok_off = 0;
@@ -219,10 +229,48 @@ struct ProfScope {
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof[idx].b, s); }
 };
 
+// fp8 form of a GEMM whose weight(s) have an e4m3 copy: quantise the rows of A on the GEMM's own stream, swap the operands
+int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
+    *done = false;
+    if (!h->fp8 || g.N % 256 || g.K % 256 || g.lda % 16) return VC_OK;
+    const auto w0 = h->fp8w.find(g.W);
+    if (w0 == h->fp8w.end()) return VC_OK;
+    VcGemmParams q = g;
+    for (int k = 1; k < g.ngroups; ++k) {
+        const auto wk = h->fp8w.find(g.Wg[k - 1]);
+        if (wk == h->fp8w.end()) return VC_OK;
+        q.Wg[k - 1] = wk->second.q;
+        q.w_scaleg[k - 1] = wk->second.scale;
+    }
+    const int64_t rows = ((int64_t)g.M + 255) / 256 * 256;
+    auto& sc = h->fp8a[s];
+    if (sc.rows < rows || sc.cols < g.K) {       // grows on the first (eager) forward of a shape; never during a graph capture
+        const int64_t nr = std::max(sc.rows, rows), ncol = std::max<int64_t>(sc.cols, g.K);
+        if (sc.q) { (void)hipStreamSynchronize(s); (void)hipFree(sc.q); (void)hipFree(sc.scale); sc = {}; }
+        if (hipMalloc(&sc.q, nr * ncol) != hipSuccess || hipMalloc((void**)&sc.scale, nr * sizeof(float)) != hipSuccess) return VC_E_NOMEM;
+        (void)hipMemsetAsync(sc.q, 0, nr * ncol, s);       // the tile rows past M are read by the kernel (never stored)
+        sc.rows = nr; sc.cols = ncol;
+    }
+    int rc = vc_launch_quantize_rows_fp8(g.A, g.lda, sc.q, g.K, sc.scale, g.M, g.K, s);
+    if (rc != VC_OK) return rc;
+    q.A = sc.q; q.lda = g.K; q.a_scale = sc.scale; q.a_rows_padded = 1;
+    q.W = w0->second.q; q.w_scale = w0->second.scale; q.ldw = g.K;
+    q.fp8 = 1; q.tile = 0;
+    rc = vc_launch_gemm(q, s);
+    if (rc == VC_E_UNSUPPORTED) return VC_OK;              // a shape the fp8 kernel does not take: the caller runs the bf16 form
+    *done = rc == VC_OK;
+    return rc;
+}
+
 int p_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, int cls = VC_PROF_GEMM) {
     const double ng = g.ngroups > 1 ? g.ngroups : 1;
     ProfScope ps(h, s, cls, ng * 2.0 * g.M * g.N * (double)g.K,
                  2.0 * ((double)g.M * g.K + ng * ((double)g.N * g.K + (double)g.M * g.N)));
+    if (h->fp8) {
+        bool done = false;
+        const int rc = fp8_gemm(h, g, s, &done);
+        if (rc != VC_OK || done) return rc;
+    }
     return vc_launch_gemm(g, s);
 }
 int p_attn(vc_engine* h, const VcAttnParams& a, hipStream_t s, int cls) {
@@ -730,6 +778,14 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     return VC_OK;
 }
 
+static void free_fp8(vc_engine* h) {
+    for (auto& kv : h->fp8w) { if (kv.second.q) (void)hipFree(kv.second.q); if (kv.second.scale) (void)hipFree(kv.second.scale); }
+    h->fp8w.clear();
+    for (auto& kv : h->fp8a) { if (kv.second.q) (void)hipFree(kv.second.q); if (kv.second.scale) (void)hipFree(kv.second.scale); }
+    h->fp8a.clear();
+    h->fp8 = false;
+}
+
 void vc_destroy(vc_engine* h) {
     if (!h) return;
     if (h->s_adp) { (void)hipStreamSynchronize(h->s_adp); (void)hipStreamDestroy(h->s_adp); }
@@ -748,8 +804,55 @@ void vc_destroy(vc_engine* h) {
     for (int l = 0; l < 2; ++l) { vc_comm_destroy(h->comm[l]); h->comm[l] = nullptr; }
     if (h->rope_dev) (void)hipFree(h->rope_dev);
     if (h->small) (void)hipFree(h->small);
+    free_fp8(h);
     delete h;
 }
+
+// BASELINE config 5's dtype for the blocks' nn.Linear layers (this build; off by default).  on != 0: every Linear of the main and
+// adapter blocks used on the step path -- self-attention q / k / v / o, cross-attention q / o, ffn.0 / ffn.2, before_proj / after_proj
+// -- gets an OCP e4m3 copy with one scale per output channel (needs every weight loaded); from then on those GEMMs quantise their
+// activations per token and run on v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation, the same fused epilogues).  Attention, norms,
+// embeddings, the per-video text K / V and the head stay bf16.  on == 0: back to bf16 (the copies are freed).
+static int build_fp8(vc_engine* h) {
+    free_fp8(h);
+    drop_graphs(h);
+    { int r = resolve(h); if (r != VC_OK) return r; }
+    const int64_t d = h->cfg.dim, f = h->cfg.ffn_dim;
+    if (d % 256 || f % 256) return fail(h, VC_E_UNSUPPORTED, "fp8 linear layers need dim and ffn_dim to be multiples of 256 (got %lld, %lld)",
+                                        (long long)d, (long long)f);
+    hipStream_t s = nullptr;
+    auto add = [&](const void* w, int64_t n, int64_t k) -> int {
+        if (!w || h->fp8w.count(w)) return VC_OK;
+        vc_engine::Fp8W q;
+        if (hipMalloc(&q.q, n * k) != hipSuccess || hipMalloc((void**)&q.scale, n * sizeof(float)) != hipSuccess)
+            return fail(h, VC_E_NOMEM, "fp8 weight copy: out of device memory");
+        h->fp8w[w] = q;
+        return vc_launch_quantize_rows_fp8(w, k, q.q, k, q.scale, (int)n, (int)k, s);
+    };
+    auto add_block = [&](const BlockW& b) -> int {
+        for (const void* w : {b.sa_q_w, b.sa_k_w, b.sa_v_w, b.sa_o_w, b.ca_q_w, b.ca_o_w, b.before_w, b.after_w})
+            VCCHK(h, add(w, d, d));
+        VCCHK(h, add(b.f0_w, f, d));
+        VCCHK(h, add(b.f2_w, d, f));
+        return VC_OK;
+    };
+    for (auto& b : h->blocks) { int r = add_block(b); if (r != VC_OK) { free_fp8(h); return r; } }
+    for (auto& b : h->gblocks) { int r = add_block(b); if (r != VC_OK) { free_fp8(h); return r; } }
+    if (hipStreamSynchronize(s) != hipSuccess) { free_fp8(h); return fail(h, VC_E_HIP, "fp8 weight quantisation: %s", hipGetErrorString(hipGetLastError())); }
+    h->fp8 = true;
+    drop_graphs(h);
+    return VC_OK;
+}
+
+int vc_set_fp8_linear(vc_engine* h, int on) {
+    if (!h) return VC_E_INVALID;
+    h->fp8_want = on != 0;
+    if (!on) { free_fp8(h); drop_graphs(h); return VC_OK; }
+    if (vc_missing_weights(h) != 0) return VC_OK;          // quantised by vc_prepare_video once every weight is there
+    return build_fp8(h);
+}
+
+int vc_fp8_linear(const vc_engine* h) { return h && h->fp8_want ? 1 : 0; }
 
 int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype, int ndim, const int64_t* shape) {
     if (!h || !key || !dev_ptr || !shape) return fail(h, VC_E_INVALID, "vc_load_weight: null argument");
@@ -763,6 +866,7 @@ int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype
     if ((uintptr_t)dev_ptr % 16) return fail(h, VC_E_INVALID, "vc_load_weight(%s): pointer not 16-byte aligned", key);
     it->second.ptr = dev_ptr;
     drop_graphs(h);
+    if (h->fp8) free_fp8(h);           // keyed by the old pointers; vc_prepare_video rebuilds them (fp8_want)
     h->resolved = false;
     h->prepared = false;   // cached cross-attention K/V depend on the weights
     return VC_OK;
@@ -902,6 +1006,7 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     if (T > 1024 || H / 2 > 1024 || Wd / 2 > 1024) return fail(h, VC_E_INVALID, "grid exceeds the 1024-row rope table");
     if (!h->rope_dev) return fail(h, VC_E_STATE, "vc_set_rope_table must be called first");
     { int r = resolve(h); if (r != VC_OK) return r; }
+    if (h->fp8_want && !h->fp8) { int r = build_fp8(h); if (r != VC_OK) return r; }      // weights were (re-)loaded since the mode was set
     Range r_prep("vc_prepare_video");
     const vc_config& c = h->cfg;
     const int d = c.dim, f = c.ffn_dim, TL = c.text_len, P = h->P;

@@ -330,7 +330,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_bf16_kernel(VcGemmParams p,
 // branches this kernel was 52 KB of code, most of it unrolled epilogue, against a 64 KB instruction cache shared by two
 // CUs; per kind it is 11-24 KB (round 2: 0-2 % at the cfg-3 shapes, same-box A/B).
 // =====================================================================================================
-template <int EPI, bool HINT = false>      // HINT: the gated-residual epilogue also adds a hint (VC.py:146-147)
+// FP8 (BASELINE config 5): the same kernel on OCP e4m3 operands.  A 128-byte LDS row then holds K = 128 elements instead of 64, and ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (32 bytes of each operand per lane: the 16-byte chunks 2g, 2g+1 of lane group g; twice the cycles of
+// a bf16 16x16x32) replaces the two bf16 MFMAs of a row: identical bytes, DMA pieces, phases and matrix-pipe cycles per K-tile at twice
+// the multiply-adds.  Block scales are 1 (e8m0 127); the per-token and per-channel scales are applied to the fp32 accumulator.
+template <int EPI, bool HINT = false, bool FP8 = false>      // HINT: the gated-residual epilogue also adds a hint (VC.py:146-147)
 __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, int nTn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int per_xcd = gridDim.x >> 3;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
         return (const char*)(((uint64_t)hi << 32) | lo);
     };
-    const int64_t lda2 = p.lda * 2, ldw2 = p.ldw * 2;      // row pitches in bytes
+    const int64_t lda2 = p.lda * (FP8 ? 1 : 2), ldw2 = p.ldw * (FP8 ? 1 : 2);      // row pitches in bytes
     // staging: per half-tile a wave moves pieces `wave` and `wave + 8` (8 LDS rows of 128 B each); both have the
     // parity of `wave`, so the lane's swizzled chunk is one constant
     const int r8 = lane >> 3;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     const char* w_src = uniform_ptr((const char*)(grp == 0 ? p.W : p.Wg[grp - 1]) +
                                     ((int64_t)n0 + (wave >> 2) * 64 + (wave & 3) * 8) * ldw2);
     const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)smem + wave * 1024);
-    const int nk = p.K >> 6;
+    const int nk = p.K >> (FP8 ? 7 : 6);                   // K-tiles of 128 bytes per row
 
     // region: 0 Ah0, 1 Ah1, 2 Bh0, 3 Bh1
     auto stage_half = [&](int stage, int region, int kt) {
@@ -389,7 +393,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
         const char* s0 = isA ? a_src + (int64_t)hh * 64 * lda2 : w_src + (int64_t)hh * 32 * ldw2;
         s0 += (int64_t)kt * 128;
         const char* s1 = s0 + 128 * (isA ? lda2 : ldw2);
-        const unsigned d0 = lds_wave + stage * 65536 + region * 16384;
+        // readfirstlane: in the FP8 instantiations hipcc (ROCm 7.2) hands this "s" operand over in a VGPR copy of the SGPR otherwise
+        const unsigned d0 = FP8 ? __builtin_amdgcn_readfirstlane(lds_wave + stage * 65536 + region * 16384) : lds_wave + stage * 65536 + region * 16384;
         unsigned keep;
         asm volatile(
             "s_mov_b32 %[keep], m0\n\t"
@@ -410,15 +415,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     // fragment reads: LDS row (within a half) of A = wr*64 + i*16 + frow, of B = wc*32 + j*16 + frow
     const int frow = lane & 15;
     const int sw = (lane >> 1) & 7;
-    const int pc0 = ((lane >> 4) ^ sw) << 4, pc1 = ((4 + (lane >> 4)) ^ sw) << 4;
+    // bf16: k-step ks reads chunk 4 ks + g; fp8: the lane's 32 consecutive bytes are the chunks 2g, 2g + 1 (g = lane >> 4)
+    const int pc0 = ((FP8 ? 2 * (lane >> 4) : (lane >> 4)) ^ sw) << 4, pc1 = ((FP8 ? 2 * (lane >> 4) + 1 : 4 + (lane >> 4)) ^ sw) << 4;
     const char* a_rd = smem + (wr * 64 + frow) * 128;
     const char* b_rd = smem + 32768 + (wc * 32 + frow) * 128;
     bf16x8 af[4][2], bf[2][2][2];       // af[i][ks] (half in use), bf[half][j][ks]
+    i32x8 a8[4], b8[2][2];              // the fp8 form: one 32-byte fragment per (i) / (half, j)
     auto read_a = [&](int stage, int hh) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc0);
-            af[i][1] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc1);
+            if constexpr (FP8) {
+                const i32x4 lo = *(const i32x4*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc0);
+                const i32x4 hi = *(const i32x4*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc1);
+                a8[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                af[i][0] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc0);
+                af[i][1] = *(const bf16x8*)(a_rd + stage * 65536 + hh * 16384 + i * 2048 + pc1);
+            }
         }
     };
     // B fragments of half hh of the K-tile in `stage` live in register set hh ^ stage: the set that held B1 of one K-tile
@@ -426,21 +439,41 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     auto read_b = [&](int stage, int hh) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bf[hh ^ stage][j][0] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
-            bf[hh ^ stage][j][1] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
+            if constexpr (FP8) {
+                const i32x4 lo = *(const i32x4*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
+                const i32x4 hi = *(const i32x4*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
+                b8[hh ^ stage][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                bf[hh ^ stage][j][0] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc0);
+                bf[hh ^ stage][j][1] = *(const bf16x8*)(b_rd + stage * 65536 + hh * 16384 + j * 2048 + pc1);
+            }
         }
     };
+    const int unit_scale = 0x7F7F7F7F;           // e8m0 127 = 1.0 for every 32-element block (fp8 form)
     auto mma = [&](int ah, int bh, int stage) {   // quadrant (A half ah, B half bh) x K=64: 16 MFMA
         const int bs = bh ^ stage;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (FP8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[ah * 4 + i][bh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[bs][j][ks], af[i][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                    // asm with a tied accumulator: through the builtin hipcc (ROCm 7.2) leaves the scaled MFMA untied (vdst != srcC for
+                    // part of them), the accumulators migrate between tuples and 110-350 VGPRs spill into the loop.  Operands come from
+                    // ds_read (the waitcnt pass covers asm inputs) and the accumulators are next read in the epilogue.
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[ah * 4 + i][bh * 2 + j])
+                                 : "v"(b8[bs][j]), "v"(a8[i]), "v"(unit_scale));
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[bs][j][ks], af[i][ks], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 #define VC_PP_BARRIER()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -503,6 +536,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     for (int kt = 0; kt < nk - 2; kt += 2) pair(kt, std::false_type{});
     pair(nk - 2, std::true_type{});
     if (wr == 0) VC_PP_BARRIER();          // equalise the barrier count
+    if constexpr (FP8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMAs: no compiler-managed wait states before the accumulators are read
     VC_PP_WAIT("s_waitcnt vmcnt(0)");      // nothing may still be landing in LDS when the workgroup retires
 #undef VC_PP_BARRIER
 #undef VC_PP_WAIT
@@ -539,6 +573,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             ggp[1][j] = *(const uint2*)(gate + (int64_t)(b_first < b_last ? b_first + 1 : b_last) * p.gate_bstride + nb + j * 16);
         }
     }
+    const float* wscale = FP8 ? (grp == 0 ? p.w_scale : p.w_scaleg[grp - 1]) + nb : nullptr;   // fp8: output-channel scales of this lane's columns
     uint2 rr[HINT ? 16 : 32], hh[16];      // residual fragments of a pass (32 without a hint, 16 + 16 hint fragments with one)
     auto pass = [&](auto i0_c, auto i1_c) __attribute__((always_inline)) {
         constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
@@ -578,6 +613,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             const bool dead = p.valid_rows >= 0 && (m - (second ? m_next : b_first * rpb)) >= p.valid_rows;
             const unsigned keep = dead ? 0u : 0xFFFFFFFFu;            // rows past valid_rows are written as +0.0
             bf16_t* crow = C + (int64_t)m * p.ldc + nst;
+            float asc = 1.f;
+            if constexpr (FP8) asc = p.a_scale[m];
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 uint2 pk[2];
@@ -585,6 +622,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = jp * 2 + jj;
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if constexpr (FP8) {
+                        const f32x4 wsj = *(const f32x4*)(wscale + j * 16);     // re-read per row: 16 more registers would spill
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= asc * wsj[e];
+                    }
                     if (bias) {
                         float bb[4];
                         unpack4(bbp[j], bb);
@@ -649,17 +691,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
 #endif
 }
 
-template <int EPI, bool HINT = false>
+template <int EPI, bool HINT = false, bool FP8 = false>
 int launch_pp_e(const VcGemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 65536;
     static std::atomic<uint64_t> attr_done{0};
-    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel<EPI, HINT>, LDS)) return VC_E_HIP;
+    if (!vc_set_lds_once(attr_done, (const void*)gemm_pp_kernel<EPI, HINT, FP8>, LDS)) return VC_E_HIP;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
     const int nTm = (p.M + 255) / 256, nTn = ng * (p.N / 256);
     const int ntiles = nTm * nTn;
     const int grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, HINT>), dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, HINT, FP8>), dim3(grid), dim3(512), LDS, stream, p, nTm, nTn, ntiles);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+int launch_pp_fp8(const VcGemmParams& p, hipStream_t stream) {
+    switch (p.epilogue) {
+        case VC_EPI_BIAS: return launch_pp_e<VC_EPI_BIAS, false, true>(p, stream);
+        case VC_EPI_BIAS_GELU: return launch_pp_e<VC_EPI_BIAS_GELU, false, true>(p, stream);
+        case VC_EPI_BIAS_RESID: return launch_pp_e<VC_EPI_BIAS_RESID, false, true>(p, stream);
+        case VC_EPI_BIAS_GATE_RESID:
+            return p.hint ? launch_pp_e<VC_EPI_BIAS_GATE_RESID, true, true>(p, stream) : launch_pp_e<VC_EPI_BIAS_GATE_RESID, false, true>(p, stream);
+    }
+    return VC_E_UNSUPPORTED;
 }
 int launch_pp(const VcGemmParams& p, hipStream_t stream) {
     switch (p.epilogue) {
@@ -948,6 +1000,21 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
 
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
+    if (p.fp8) {      // e4m3 operands: the ping-pong kernel or nothing
+        if (!p.a_scale || !p.w_scale) return VC_E_INVALID;
+        for (int g = 1; g < p.ngroups; ++g)
+            if (!p.Wg[g - 1] || !p.Cg[g - 1] || !p.w_scaleg[g - 1]) return VC_E_INVALID;
+        const bool rows_ok8 = (p.M % 256 == 0) || p.a_rows_padded;
+        bool ok = rows_ok8 && p.N % 256 == 0 && p.K % 256 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.ldc % 8 == 0 &&
+                  ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 &&
+                  (p.rows_per_batch == 0 || p.rows_per_batch >= 256) && p.lda * 256 < (1ll << 31) && p.ldw * 256 < (1ll << 31) &&
+                  ((uintptr_t)p.w_scale & 15) == 0;
+        if (p.resid) ok = ok && p.ldr % 8 == 0 && ((uintptr_t)p.resid & 15) == 0;
+        if (p.hint) ok = ok && p.ldh % 8 == 0 && ((uintptr_t)p.hint & 15) == 0;
+        if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID) && !p.resid) return VC_E_INVALID;
+        if (p.epilogue == VC_EPI_BIAS_GATE_RESID && !p.gate) return VC_E_INVALID;
+        return ok ? launch_pp_fp8(p, stream) : VC_E_UNSUPPORTED;
+    }
     if (p.K % 64 != 0 || p.N % 4 != 0) return VC_E_UNSUPPORTED;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 4)) return VC_E_UNSUPPORTED;
     if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID || p.epilogue == VC_EPI_GELU_MUL) && (!p.resid || p.ldr % 4))

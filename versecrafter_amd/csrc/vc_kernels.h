@@ -38,8 +38,16 @@ struct VcGemmParams {
     int a_rows_padded;               // rows of A up to the next multiple of 256 are readable (engine workspace)
     int valid_rows;                  // >= 0: rows with (m % rows_per_batch) >= valid_rows are written as 0; < 0: off
     int tile;                        // kernel selection for tests / tuning (0 = auto; see vc_launch_gemm)
+    // fp8 operands (BASELINE config 5's dtype; block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales): A and W hold OCP
+    // e4m3 bytes ([M, K] / [N, K]; lda / ldw in elements = bytes), C = (A W^T) * a_scale[m] * w_scale[n], then the epilogue as for bf16.
+    // Ping-pong kernel only: M padded / % 256, N % 256, K % 256.
+    int fp8;
+    const float* a_scale;            // [M] per row (token) of A
+    const float* w_scale;            // [N] per row (output channel) of W; groups g > 0: w_scaleg[g - 1]
+    const float* w_scaleg[2];
 };
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream);
+int vc_launch_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, hipStream_t stream);
 
 // ---- attention: out[b, i, h, :] = softmax(q k^T * scale) v ----------------------------------
 struct VcAttnParams {

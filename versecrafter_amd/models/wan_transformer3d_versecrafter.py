@@ -327,6 +327,17 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
                                 rope_params(1024, 2 * (self.d // 6))], dim=1)
         self._rope_dirty = True
 
+    def enable_fp8_linear(self, on: bool = True):
+        """(this build; BASELINE config 5's dtype -- the reference computes in bf16 and has no such mode) Run the nn.Linear layers of the
+        main and adapter blocks in fp8: OCP e4m3 weights with one scale per output channel, activations quantised per token in front of
+        each GEMM, v_mfma_scale_f32_16x16x128_f8f6f4 with fp32 accumulation and the same fused epilogues.  Attention, norms,
+        embeddings, the per-video text K / V and the head stay bf16.  The bf16 parameters stay where they are (the engine keeps its
+        own e4m3 copies: + 1 byte per parameter of those layers)."""
+        self._fp8_linear = bool(on)
+        if self._engine is not None:
+            _lib.check(_lib.load().vc_set_fp8_linear(self._engine, int(self._fp8_linear)), self._engine)
+            self._video_key = self._video_ident = None
+
     def enable_multi_gpus_inference(self, sp_group=None, batch_group=None):
         """WT.py:901-921: switch self-attention of blocks and geoada_blocks to the Ulysses exchange.
         `sp_group`: a torch.distributed group (default: the one set_multi_gpus_devices made), or an object with
@@ -411,6 +422,8 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             h = C.c_void_p()
             _lib.check(lib.vc_create(C.byref(cfg), C.byref(h)))
             self._engine = h
+            if getattr(self, "_fp8_linear", False):
+                _lib.check(lib.vc_set_fp8_linear(h, 1), h)        # copies are built once the weights are loaded (vc_prepare_video)
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):                                      # .to() / .cuda() / .bfloat16(): parameters move

@@ -47,6 +47,36 @@ def gemm(a, w, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, rows_per_bat
     return out
 
 
+def quantize_rows_fp8(x):
+    """bf16 [M, K] -> (OCP e4m3 bytes as uint8 [M, K], float32 scale [M]): x ~ q * scale[:, None], scale = amax / 448 per row."""
+    lib = _lib.load()
+    _chk(x, "x")
+    M, K = x.shape
+    assert x.stride(1) == 1
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vc_op_quantize_rows_fp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(sc), M, K, _stream()))
+    return q, sc
+
+
+def gemm_fp8(a_q, a_scale, w_q, w_scale, bias=None, epilogue=EPI_BIAS, resid=None, gate=None, rows_per_batch=0, out=None, a_rows_padded=False):
+    """out[M,N] bf16 = epilogue((a_q[M,K] @ w_q[N,K]^T) * a_scale[:, None] * w_scale[None, :] + bias) on e4m3 operands (uint8 storage):
+    v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation.  BASELINE config 5's dtype; a capability of this build, off by default."""
+    lib = _lib.load()
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    assert a_q.dtype == torch.uint8 and w_q.dtype == torch.uint8 and w_q.shape[1] == K and a_q.stride(1) == 1 and w_q.stride(1) == 1
+    assert a_scale.dtype == torch.float32 and w_scale.dtype == torch.float32 and a_scale.numel() == M and w_scale.numel() == N
+    _chk(bias, "bias"); _chk(resid, "resid"); _chk(gate, "gate")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a_q.device)
+    rc = lib.vc_op_gemm_fp8(_ptr(a_q), a_q.stride(0), _ptr(a_scale), _ptr(w_q), w_q.stride(0), _ptr(w_scale), _ptr(out), out.stride(0),
+                            _ptr(bias), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate),
+                            0 if gate is None else gate.stride(0), rows_per_batch, 1 if a_rows_padded else 0, _stream())
+    _lib.check(rc)
+    return out
+
+
 def attention(q, k, v, k_len=0, scale=None, out=None, variant=0):
     """q [B,Lq,H,128], k/v [B,Lk,H,128] (any strides with a contiguous last dim) -> [B,Lq,H,128].
     variant (tests / A-B tools): MFMA shape of the pipelined kernel, 32 or 16; 0 = the library's default."""
