@@ -244,8 +244,11 @@ int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
     }
     const int64_t rows = ((int64_t)g.M + 255) / 256 * 256;
     auto& sc = h->fp8a[s];
-    if (sc.rows < rows || sc.cols < g.K) {       // grows on the first (eager) forward of a shape; never during a graph capture
-        const int64_t nr = std::max(sc.rows, rows), ncol = std::max<int64_t>(sc.cols, g.K);
+    if (sc.rows < rows || sc.cols < g.K) {
+        // sized once per stream for the largest operand of the prepared video (all samples' rows x ffn_dim), so that no later call --
+        // a different batch under cfg_skip, a forward that is being captured into a graph -- ever allocates
+        const int64_t nr = std::max({sc.rows, rows, ((int64_t)h->M + 255) / 256 * 256});
+        const int64_t ncol = std::max({sc.cols, (int64_t)g.K, (int64_t)h->cfg.ffn_dim});
         if (sc.q) { (void)hipStreamSynchronize(s); (void)hipFree(sc.q); (void)hipFree(sc.scale); sc = {}; }
         if (hipMalloc(&sc.q, nr * ncol) != hipSuccess || hipMalloc((void**)&sc.scale, nr * sizeof(float)) != hipSuccess) return VC_E_NOMEM;
         (void)hipMemsetAsync(sc.q, 0, nr * ncol, s);       // the tile rows past M are read by the kernel (never stored)
