@@ -353,6 +353,12 @@ def test_cli_runs_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     two = load_file(os.path.join(str(tmp_path / "moe"), "generated_latents_0.safetensors"))["latents"]
     assert two.shape == out.shape and torch.isfinite(two).all() and not torch.equal(two, out)
+    # fp8 linear layers through the CLI: eight sampler steps later the latents are still the bf16 run's, up to the quantisation drift
+    r = subprocess.run(cmd + ["--fp8_linear", "1", "--save_path", str(tmp_path / "fp8")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    q = load_file(os.path.join(str(tmp_path / "fp8"), "generated_latents_0.safetensors"))["latents"]
+    drift = ((q.float() - out.float()).norm() / out.float().norm()).item()
+    assert torch.isfinite(q).all() and 1e-4 < drift < 0.25, drift
 
 
 @pytest.mark.parametrize("name,dims,grid", [
