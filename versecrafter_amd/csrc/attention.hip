@@ -261,6 +261,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[0], 0, 0, 0);
             S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[(ks + 1) & 7], S[1], 0, 0, 0);
         }
+#elif VC_ATTN_ABLATE == 4      // timing ablation only (wrong results): half of the QK^T MFMAs and K fragment reads = the matrix-pipe cycles and LDS bytes of an fp8 QK^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
+            }
+        }
 #else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
