@@ -773,6 +773,37 @@ def test_fp8_linear_mode(model):
     assert torch.equal(model(x, t, geo, ctx, 72), ref)
 
 
+@pytest.mark.parametrize("width", ["tiny", "14b"])
+def test_fp8_layernorm_fusion_is_bit_equal_to_the_separate_quantiser(width, monkeypatch):
+    """In fp8 mode the three LayerNorms of a block that feed only GEMMs (norm1 -> q/k/v, norm3 -> cross q, norm2 -> ffn.0) write the
+    GEMM's e4m3 operand themselves (no bf16 row, no quantiser pass).  Same bytes, same scales: the forward is bit-equal to the
+    unfused form (VC_FP8_FUSE_LN=0)."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dev = torch.device("cuda", 0)
+    dims = dict(TINY) if width == "tiny" else dict(geoada_in_dim=128, dim=5120, ffn_dim=13824, num_heads=40, num_layers=2)
+    T, h, w = (3, 8, 12) if width == "tiny" else (2, 16, 48)
+    td = dims.get("text_dim", 4096)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    geo = torch.randn(2, 128, T, h, w, generator=g).to(dev, torch.bfloat16)
+    ctx = [torch.randn(20, td, generator=g).to(dev, torch.bfloat16), torch.randn(33, td, generator=g).to(dev, torch.bfloat16)]
+    t = torch.tensor([640.0, 640.0], device=dev)
+    L = T * (h // 2) * (w // 2)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("VC_FP8_FUSE_LN", fuse)                   # read at vc_create
+        torch.manual_seed(0)
+        m = VerseCrafterWanTransformer3DModel(param_device=dev, param_dtype=torch.bfloat16, skip_init=True, **dims)
+        m.init_weights(zero_init_outputs=False)
+        m.enable_fp8_linear()
+        outs.append(m(x, t, geo, ctx, L).clone())
+        outs.append(m(x, t, geo, ctx, L).clone())                    # second call: graph replay where the model is small enough
+        del m
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 1e-3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[2], outs[3])
+
+
 def test_fp8_linear_at_the_14b_width_against_bf16():
     """The same at the production width (d = 5120, 40 heads, ffn 13824; 2 + 1 blocks, 768 tokens): every fp8 GEMM shape of the real
     model, against the bf16 engine."""

@@ -124,7 +124,13 @@ struct vc_engine {
     // the blocks' nn.Linear weights, keyed by the bf16 weight pointer; activations are quantised per token in front of every such GEMM
     // into a per-stream scratch (rows padded to the GEMM's 256-row tiles).
     struct Fp8W { void* q = nullptr; float* scale = nullptr; };
-    struct Fp8Scratch { void* q = nullptr; float* scale = nullptr; int64_t rows = 0, cols = 0; };
+    struct Fp8Scratch {
+        void* q = nullptr; float* scale = nullptr; int64_t rows = 0, cols = 0;
+        // set by a LayerNorm that wrote its row straight into this scratch (ln_out): the very next fp8 GEMM on the stream whose A is
+        // `fresh_for` (the bf16 buffer the LayerNorm did NOT write) takes the operand as it is
+        const void* fresh_for = nullptr; int fresh_M = 0, fresh_K = 0;
+    };
+    bool fp8_fuse_ln = true;        // VC_FP8_FUSE_LN=0 at vc_create: LayerNorm writes bf16 and the GEMM quantises (tests: bit-equal)
     bool fp8 = false;               // the copies exist
     bool fp8_want = false;          // the mode is on (copies are rebuilt by vc_prepare_video after a weight was re-loaded)
     std::unordered_map<const void*, Fp8W> fp8w;
@@ -229,6 +235,7 @@ struct ProfScope {
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->prof[idx].b, s); }
 };
 
+int fp8_scratch(vc_engine* h, hipStream_t s, int M, int K);
 // fp8 form of a GEMM whose weight(s) have an e4m3 copy: quantise the rows of A on the GEMM's own stream, swap the operands
 int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
     *done = false;
@@ -242,27 +249,54 @@ int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
         q.Wg[k - 1] = wk->second.q;
         q.w_scaleg[k - 1] = wk->second.scale;
     }
-    const int64_t rows = ((int64_t)g.M + 255) / 256 * 256;
+    int rc = fp8_scratch(h, s, g.M, g.K);
+    if (rc != VC_OK) return rc;
     auto& sc = h->fp8a[s];
-    if (sc.rows < rows || sc.cols < g.K) {
+    const bool fresh = sc.fresh_for == g.A && sc.fresh_M == g.M && sc.fresh_K == g.K;
+    sc.fresh_for = nullptr;
+    if (!fresh) {
+        rc = vc_launch_quantize_rows_fp8(g.A, g.lda, sc.q, g.K, sc.scale, g.M, g.K, s);
+        if (rc != VC_OK) return rc;
+    }
+    q.A = sc.q; q.lda = g.K; q.a_scale = sc.scale; q.a_rows_padded = 1;
+    q.W = w0->second.q; q.w_scale = w0->second.scale; q.ldw = g.K;
+    q.fp8 = 1; q.tile = 0;
+    rc = vc_launch_gemm(q, s);
+    if (rc == VC_E_UNSUPPORTED && !fresh) return VC_OK;    // a shape the fp8 kernel does not take: the caller runs the bf16 form
+    *done = rc == VC_OK;                                   // (after a fused LayerNorm there is no bf16 operand to fall back to: error)
+    return rc;
+}
+
+// the stream's quantised-A scratch, at least rows x cols
+int fp8_scratch(vc_engine* h, hipStream_t s, int M, int K) {
+    const int64_t rows = ((int64_t)M + 255) / 256 * 256;
+    auto& sc = h->fp8a[s];
+    if (sc.rows < rows || sc.cols < K) {
         // sized once per stream for the largest operand of the prepared video (all samples' rows x ffn_dim), so that no later call --
         // a different batch under cfg_skip, a forward that is being captured into a graph -- ever allocates
         const int64_t nr = std::max({sc.rows, rows, ((int64_t)h->M + 255) / 256 * 256});
-        const int64_t ncol = std::max({sc.cols, (int64_t)g.K, (int64_t)h->cfg.ffn_dim});
+        const int64_t ncol = std::max({sc.cols, (int64_t)K, (int64_t)h->cfg.ffn_dim});
         if (sc.q) { (void)hipStreamSynchronize(s); (void)hipFree(sc.q); (void)hipFree(sc.scale); sc = {}; }
         if (hipMalloc(&sc.q, nr * ncol) != hipSuccess || hipMalloc((void**)&sc.scale, nr * sizeof(float)) != hipSuccess) return VC_E_NOMEM;
         (void)hipMemsetAsync(sc.q, 0, nr * ncol, s);       // the tile rows past M are read by the kernel (never stored)
         sc.rows = nr; sc.cols = ncol;
     }
-    int rc = vc_launch_quantize_rows_fp8(g.A, g.lda, sc.q, g.K, sc.scale, g.M, g.K, s);
-    if (rc != VC_OK) return rc;
-    q.A = sc.q; q.lda = g.K; q.a_scale = sc.scale; q.a_rows_padded = 1;
-    q.W = w0->second.q; q.w_scale = w0->second.scale; q.ldw = g.K;
-    q.fp8 = 1; q.tile = 0;
-    rc = vc_launch_gemm(q, s);
-    if (rc == VC_E_UNSUPPORTED) return VC_OK;              // a shape the fp8 kernel does not take: the caller runs the bf16 form
-    *done = rc == VC_OK;
-    return rc;
+    return VC_OK;
+}
+
+// LayerNorm whose output only feeds the GEMM with weight `next_w`: in fp8 mode the row goes straight to that GEMM's e4m3 operand
+int ln_out(vc_engine* h, const void* x, void* y, int M, int d, int rpb, float eps, int mode, const void* p0, const void* p1, int64_t bstride,
+           const void* next_w, hipStream_t s) {
+    if (h->fp8 && h->fp8_fuse_ln && d % 256 == 0 && h->fp8w.count(next_w)) {
+        int rc = fp8_scratch(h, s, M, d);
+        if (rc != VC_OK) return rc;
+        auto& sc = h->fp8a[s];
+        rc = vc_launch_layernorm_q8(x, sc.q, sc.scale, M, d, rpb, eps, mode, p0, p1, bstride, s);
+        if (rc != VC_OK) return rc;
+        sc.fresh_for = y; sc.fresh_M = M; sc.fresh_K = d;
+        return VC_OK;
+    }
+    return vc_launch_layernorm(x, y, M, d, rpb, eps, mode, p0, p1, bstride, s);
 }
 
 int p_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, int cls = VC_PROF_GEMM) {
@@ -597,7 +631,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
     // e = modulation + e0  (WT.py:588)
     VCCHK(h, vc_launch_modulation(w.modulation, e0, ln.mod, B, 6, d, 6 * d, d, s));
     // t = norm1(x) * (1 + e1) + e0  (WT.py:591)
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, Ms, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * Ms * d); VCCHK(h, ln_out(h, xs, ln.tb, Ms, d, Lloc, eps, 0, modp(1), modp(0), 6 * d, w.sa_q_w, s)); }
     // q, k, v projections into [M, 3d]  (WT.py:385-387): one grouped launch (3 problems sharing A)
     {
         VcGemmParams g = gemm(ln.tb, d, w.sa_q_w, w.sa_q_b, ln.qkv, 3 * d, Ms, d, d);
@@ -628,7 +662,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         for (int b = 1; b < B; ++b)
             HIPCHK(h, hipMemcpyAsync((char*)xs + (int64_t)b * Lloc * d * 2, xs, (int64_t)Lloc * d * 2, hipMemcpyDeviceToDevice, s));
     // cross attention: x = x + o(attn(rms(q(norm3(x))), K, V))  (WT.py:600, 410-436)
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, ln_out(h, xs, ln.tb, M, d, 0, eps, 1, w.n3_w, w.n3_b, 0, w.ca_q_w, s)); }
     {
         VcGemmParams g = gemm(ln.tb, d, w.ca_q_w, w.ca_q_b, ln.qkv, d, M, d, d);
         VCCHK(h, p_gemm(h, g, s));
@@ -653,7 +687,7 @@ int run_block(vc_engine* h, const BlockW& w, void* xs, const void* hint, float h
         VCCHK(h, p_gemm(h, g, s));
     }
     // ffn: x = x + ffn(norm2(x) * (1 + e4) + e3) * e5  (WT.py:603-607)  [+ hint * scale, VC.py:147]
-    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, vc_launch_layernorm(xs, ln.tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, s)); }
+    { ProfScope ps(h, s, VC_PROF_ROW, 0, 4.0 * M * d); VCCHK(h, ln_out(h, xs, ln.tb, M, d, Lloc, eps, 0, modp(4), modp(3), 6 * d, w.f0_w, s)); }
     {
         VcGemmParams g = gemm(ln.tb, d, w.f0_w, w.f0_b, ln.hb, f, M, f, d, VC_EPI_BIAS_GELU);
         VCCHK(h, p_gemm(h, g, s));
@@ -711,6 +745,7 @@ int vc_create(const vc_config* cfg, vc_engine** out) {
     h->pad_merge = getenv("VC_NO_PAD_MERGE") == nullptr;
     if (const char* rx = getenv("VC_ROCTX")) if (atoi(rx) == 1) roctx_enable();
     if (const char* gm = getenv("VC_GRAPH")) h->graph_mode = atoi(gm) != 0;
+    if (const char* fl = getenv("VC_FP8_FUSE_LN")) h->fp8_fuse_ln = atoi(fl) != 0;
     if (cfg->num_geoada_layers > 0) {
         if (cfg->num_geoada_layers > VC_MAX_GEOADA_LAYERS) { delete h; return fail(nullptr, VC_E_INVALID, "too many geoada layers"); }
         h->geoada_layers.assign(cfg->geoada_layers, cfg->geoada_layers + cfg->num_geoada_layers);

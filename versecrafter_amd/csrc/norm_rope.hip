@@ -16,11 +16,15 @@ namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;
 
-template <int MAXC>
+// Q8 (fp8 linear layers, vc_set_fp8_linear): the row is NOT written as bf16 but as the e4m3 operand of the GEMM it feeds -- bytes
+// q[row][dim] + one scale per row, exactly what quantize_rows_fp8_kernel makes of the bf16 row (amax / 448, RNE) -- so the quantiser's
+// pass over the row (2 bytes read + 1 written per element) and the bf16 write (2 bytes) disappear.
+template <int MAXC, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                         int rows, int dim, int rows_per_batch, float eps, int mode,
                                                         const bf16_t* __restrict__ p0,
-                                                        const bf16_t* __restrict__ p1, int64_t p_bstride) {
+                                                        const bf16_t* __restrict__ p1, int64_t p_bstride,
+                                                        uint8_t* __restrict__ q = nullptr, float* __restrict__ qscale = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * ROWS_PER_BLOCK + wave;
     if (row >= rows) return;
@@ -77,7 +81,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                 else             // fp32 affine inside F.layer_norm, one rounding at the end
                     f[e] = n * a[e] + bb[e];
             }
-            *(uint4*)(yr + idx) = pack8(f);
+            if constexpr (Q8) raw[c] = pack8(f);         // the bf16 row, kept in the registers that held the input row
+            else *(uint4*)(yr + idx) = pack8(f);
+        }
+    }
+    if constexpr (Q8) {
+        float amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int idx = c * 512 + lane * 8;
+            if (idx < dim) {
+                float f[8];
+                unpack8(raw[c], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / sc;
+        if (lane == 0) qscale[row] = sc;
+        uint8_t* qr = q + (int64_t)row * dim;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int idx = c * 512 + lane * 8;
+            if (idx < dim) {
+                float f[8];
+                unpack8(raw[c], f);
+                unsigned out[2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2 * e] * inv, f[2 * e + 1] * inv, 0, false);
+                    if (e & 1) out[e >> 1] |= ((unsigned)pk & 0xFFFFu) << 16;
+                    else out[e >> 1] = (unsigned)pk & 0xFFFFu;
+                }
+                *(uint2*)(qr + idx) = uint2{out[0], out[1]};
+            }
         }
     }
 }
@@ -278,6 +317,22 @@ int vc_launch_layernorm(const void* x, void* y, int rows, int dim, int rows_per_
     else if (dim <= 5120) LN_LAUNCH(10);
     else LN_LAUNCH(16);
 #undef LN_LAUNCH
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+int vc_launch_layernorm_q8(const void* x, void* q, float* qscale, int rows, int dim, int rows_per_batch, float eps, int mode,
+                           const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream) {
+    if (!x || !q || !qscale || !p0 || !p1 || rows <= 0 || dim <= 0) return VC_E_INVALID;
+    if (dim % 8 || dim > 8192 || (p_bstride % 8) || ((uintptr_t)q & 7)) return VC_E_UNSUPPORTED;
+    const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+#define LNQ_LAUNCH(MC)                                                                                               \
+    hipLaunchKernelGGL((layernorm_kernel<MC, true>), grid, block, 0, stream, (const bf16_t*)x, (bf16_t*)nullptr, rows, dim, \
+                       rows_per_batch, eps, mode, (const bf16_t*)p0, (const bf16_t*)p1, p_bstride, (uint8_t*)q, qscale)
+    if (dim <= 512) LNQ_LAUNCH(1);
+    else if (dim <= 2048) LNQ_LAUNCH(4);
+    else if (dim <= 5120) LNQ_LAUNCH(10);
+    else LNQ_LAUNCH(16);
+#undef LNQ_LAUNCH
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 

@@ -47,6 +47,8 @@ struct VcGemmParams {
     const float* w_scaleg[2];
 };
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream);
+int vc_launch_layernorm_q8(const void* x, void* q, float* qscale, int rows, int dim, int rows_per_batch, float eps, int mode,
+                           const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream);
 int vc_launch_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, hipStream_t stream);
 
 // ---- attention: out[b, i, h, :] = softmax(q k^T * scale) v ----------------------------------
