@@ -270,6 +270,15 @@ int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
 // the stream's quantised-A scratch, at least rows x cols
 int fp8_scratch(vc_engine* h, hipStream_t s, int M, int K) {
     const int64_t rows = ((int64_t)M + 255) / 256 * 256;
+    if (!h->fp8a.count(s) && h->fp8a.size() >= 8) {
+        // a caller that keeps changing streams: the engine itself uses at most five (caller, adapter, two exchange lanes, capture)
+        for (auto& kv : h->fp8a) {
+            (void)hipStreamSynchronize(kv.first);
+            if (kv.second.q) (void)hipFree(kv.second.q);
+            if (kv.second.scale) (void)hipFree(kv.second.scale);
+        }
+        h->fp8a.clear();
+    }
     auto& sc = h->fp8a[s];
     if (sc.rows < rows || sc.cols < K) {
         // sized once per stream for the largest operand of the prepared video (all samples' rows x ffn_dim), so that no later call --
