@@ -95,10 +95,10 @@ def get_point_cloud_from_depth(depth: torch.Tensor, intrinsic: torch.Tensor, ext
 def fit_3d_gaussian(points: torch.Tensor, device: str = "cuda") -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """(N, 3) points -> (mean (3,), covariance (3, 3) = unbiased sample covariance + 1e-6 I), or (None, None) below 3 points."""
     if len(points) == 0:
-        logger.warning("Empty point cloud, cannot fit Gaussian")
+        logger.warning("fit_3d_gaussian: empty point cloud")
         return None, None
     if len(points) < 3:
-        logger.warning(f"Too few points ({len(points)}), cannot reliably fit Gaussian")
+        logger.warning(f"fit_3d_gaussian: {len(points)} points are too few")
         return None, None
     points = _need_cuda(points, "fit_3d_gaussian").float()
     dev = points.device
@@ -119,7 +119,7 @@ def load_mask(mask_path: str, device: str = "cuda", erode_kernel_size: int = 5) 
             raise ValueError(f"expected a single-channel mask, got shape {raw.shape}")
         return erode_mask(torch.from_numpy(raw).to(device), erode_kernel_size)
     except Exception as e:  # the reference logs and skips an unreadable mask (:157-159)
-        logger.error(f"Failed to load mask {mask_path}: {e}")
+        logger.error(f"{mask_path}: {e}")
         return None
 
 
@@ -252,118 +252,119 @@ def visualize_gaussian_projections(gaussian_params: Dict[int, Dict], intrinsic, 
             Image.fromarray(overlay, mode="RGB").save(output_path / "gaussian_overlay_on_image.png")
             logger.info(f"Saved Gaussian overlay to {output_path / 'gaussian_overlay_on_image.png'}")
         except Exception as e:
-            logger.warning(f"Failed to generate overlay image: {e}")
+            logger.warning(f"overlay picture not written: {e}")
     return obj_id_to_color_idx
 
 
 def tensor_to_json_serializable(t):
+    """Tensors / arrays -> nested lists for json (anything else passes through)."""
     if isinstance(t, torch.Tensor):
-        return t.cpu().detach().numpy().tolist()
-    if isinstance(t, np.ndarray):
-        return t.tolist()
-    return t
+        t = t.detach().cpu().numpy()
+    return t.tolist() if isinstance(t, np.ndarray) else t
 
 
 # ----------------------------------------------------------------------------------------------------------- :450-630
+def _read_depth_npz(npz_path, device):
+    """depth_intrinsics.npz (MoGe's output) -> (depth float32 (H, W) on the device, intrinsic 3x3 in PIXELS, depth array shape).
+    A leading batch axis is dropped; normalised intrinsics (focal < 10) are scaled by the image size (:479-512)."""
+    with np.load(npz_path) as z:
+        depth_np = np.asarray(z["depth"], dtype=np.float32)
+        k_np = np.asarray(z["intrinsic"], dtype=np.float32)
+    depth_np = depth_np[0] if depth_np.ndim == 3 else depth_np
+    k_np = k_np[0] if k_np.ndim == 3 else k_np
+    depth = torch.from_numpy(np.ascontiguousarray(depth_np)).to(device)
+    K = torch.from_numpy(np.ascontiguousarray(k_np)).to(device).clone()
+    rows, cols = depth.shape
+    if min(abs(float(K[0, 0])), abs(float(K[1, 1]))) < 10:
+        K[0, 0] *= cols
+        K[0, 2] *= cols
+        K[1, 1] *= rows
+        K[1, 2] *= rows
+    return depth, K, depth_np.shape[:2]
+
+
+def _fit_one_object(mask_file, depth, K, E, device):
+    """One mask_NN_<label>.png -> (object id, its gaussian_params entry) or (id, None) when the object is skipped (:530-583)."""
+    fields = mask_file.stem.split("_")
+    obj_id = int(fields[1])
+    label = "_".join(fields[2:]) or f"object_{obj_id}"
+    mask = load_mask(str(mask_file), device=device)
+    if mask is None:
+        logger.warning(f"{mask_file.name}: unreadable mask, object skipped")
+        return obj_id, None
+    pts = get_point_cloud_from_depth(depth, K, E, mask)
+    if len(pts) < 10:
+        logger.warning(f"{label} (ID {obj_id}): only {len(pts)} points under the mask, object skipped")
+        return obj_id, None
+    mean, cov = fit_3d_gaussian(pts, device)
+    if mean is None:
+        logger.warning(f"{label} (ID {obj_id}): no Gaussian could be fitted, object skipped")
+        return obj_id, None
+    spectrum = torch.linalg.eigvalsh(cov.double().cpu()).float()                 # 3 x 3, reporting only
+    logger.info(f"{label} (ID {obj_id}): {len(pts)} points, mean {mean.cpu().numpy()}, covariance trace {float(cov.trace()):.6f}")
+    return obj_id, {
+        "label": label,
+        "mean": tensor_to_json_serializable(mean),
+        "cov": tensor_to_json_serializable(cov),
+        "num_points": len(pts),
+        "num_mask_pixels": int(mask.sum().item()),
+        "eigvals": tensor_to_json_serializable(spectrum),
+        "trace": float(cov.trace()),
+    }
+
+
 def process_single_image(npz_path: str, masks_dir: str, output_dir: str, device: str = "cuda", input_image_path: Optional[str] = None,
                          enable_visualization: bool = True):
     """depth_intrinsics.npz + masks/mask_NN_<label>.png -> <output_dir>/gaussian_params.json (+ the two pictures); returns the dict
     that was written (None when the inputs are unusable, like the reference)."""
-    output_path = Path(output_dir)
-    output_path.mkdir(parents=True, exist_ok=True)
-    logger.info(f"Loading NPZ file: {npz_path}")
+    out_dir = Path(output_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
     try:
-        data = np.load(npz_path)
-        depth_np = data["depth"].astype(np.float32)
-        intrinsic_np = data["intrinsic"].astype(np.float32)
-        if depth_np.ndim == 3:
-            depth_np = depth_np[0]
-        if intrinsic_np.ndim == 3:
-            intrinsic_np = intrinsic_np[0]
+        depth, K, depth_shape = _read_depth_npz(npz_path, device)
     except Exception as e:
-        logger.error(f"Failed to load NPZ: {e}")
+        logger.error(f"{npz_path}: cannot read depth / intrinsic ({e})")
         return None
-    depth = torch.from_numpy(depth_np).to(device)
-    intrinsic = torch.from_numpy(intrinsic_np).to(device)
-    extrinsic = torch.eye(4, device=device, dtype=torch.float32)     # the camera of the first frame is the world origin (:494)
-    h, w = depth.shape
-    fx, fy = intrinsic[0, 0].item(), intrinsic[1, 1].item()
-    if abs(fx) < 10 or abs(fy) < 10:                                  # normalised intrinsics (MoGe's output) -> pixels (:508-512)
-        intrinsic[0, 0] *= w
-        intrinsic[1, 1] *= h
-        intrinsic[0, 2] *= w
-        intrinsic[1, 2] *= h
-    masks_path = Path(masks_dir)
-    if not masks_path.exists():
-        logger.error(f"Masks directory does not exist: {masks_dir}")
-        return None
-    mask_files = sorted(masks_path.glob("mask_*.png"))
-    logger.info(f"Found {len(mask_files)} mask files")
+    E = torch.eye(4, device=device, dtype=torch.float32)             # the camera of the first frame is the world origin (:494)
+    rows, cols = depth.shape
+    mask_files = sorted(Path(masks_dir).glob("mask_*.png")) if Path(masks_dir).is_dir() else []
     if not mask_files:
-        logger.error("No mask files found")
+        logger.error(f"{masks_dir}: no mask_*.png files")
         return None
 
-    gaussian_params = {}
-    for mask_file in mask_files:
+    fitted = {}
+    for mf in mask_files:
         try:
-            parts = mask_file.stem.split("_")
-            obj_id = int(parts[1])
-            obj_label = "_".join(parts[2:]) if len(parts) > 2 else f"object_{obj_id}"
-            mask = load_mask(str(mask_file), device=device)
-            if mask is None:
-                logger.warning(f"Skipping invalid mask: {mask_file.name}")
-                continue
-            num_pixels = mask.sum().item()
-            points = get_point_cloud_from_depth(depth, intrinsic, extrinsic, mask)
-            num_points = len(points)
-            if num_points < 10:
-                logger.warning(f"{obj_label} (ID {obj_id}): too few points, skipping this object")
-                continue
-            mean, cov = fit_3d_gaussian(points, device)
-            if mean is None or cov is None:
-                logger.warning(f"{obj_label} (ID {obj_id}): Gaussian fitting failed, skipping this object")
-                continue
-            eigvals = torch.linalg.eigvalsh(cov.double().cpu()).float()          # 3x3, reporting only
-            trace = cov.trace()
-            logger.info(f"{obj_label} (ID {obj_id}): {num_points} points, mean {mean.cpu().numpy()}, covariance trace {trace.item():.6f}")
-            gaussian_params[obj_id] = {
-                "label": obj_label,
-                "mean": tensor_to_json_serializable(mean),
-                "cov": tensor_to_json_serializable(cov),
-                "num_points": num_points,
-                "num_mask_pixels": num_pixels,
-                "eigvals": tensor_to_json_serializable(eigvals),
-                "trace": trace.item(),
-            }
-        except Exception as e:
-            logger.error(f"Failed to process mask {mask_file.name}: {e}")
+            obj_id, entry = _fit_one_object(mf, depth, K, E, device)
+        except Exception as e:                                       # the reference logs and goes on with the next mask (:585-587)
+            logger.error(f"{mf.name}: {e}")
             continue
+        if entry is not None:
+            fitted[obj_id] = entry
 
-    obj_id_to_color_idx = {}
+    colour_of = {obj_id: i for i, obj_id in enumerate(sorted(fitted))}          # without pictures: by id (:606-611)
     if enable_visualization:
-        if gaussian_params:
+        colour_of = {}
+        if fitted:
             try:
-                obj_id_to_color_idx = visualize_gaussian_projections(
-                    gaussian_params=gaussian_params, intrinsic=intrinsic, extrinsic=extrinsic, image_size=(w, h), output_path=output_path,
-                    probability_threshold=0.97, device=device, input_image_path=input_image_path)
+                colour_of = visualize_gaussian_projections(gaussian_params=fitted, intrinsic=K, extrinsic=E, image_size=(cols, rows),
+                                                           output_path=out_dir, probability_threshold=0.97, device=device,
+                                                           input_image_path=input_image_path)
             except Exception as e:
-                logger.warning(f"Visualization generation failed: {e}")
+                logger.warning(f"pictures not written: {e}")
         else:
-            logger.warning("No objects detected, skipping visualization")
-    else:
-        obj_id_to_color_idx = {obj_id: i for i, obj_id in enumerate(sorted(gaussian_params))}
+            logger.warning("nothing was fitted: no pictures")
 
-    output_data = {
-        "image_info": {"resolution": [int(w), int(h)], "depth_shape": depth_np.shape[:2]},
-        "camera_info": {"intrinsic": tensor_to_json_serializable(intrinsic), "extrinsic": tensor_to_json_serializable(extrinsic)},
-        "gaussian_params": gaussian_params,
-        "num_objects": len(gaussian_params),
-        "obj_id_to_color_idx": obj_id_to_color_idx,
+    result = {
+        "image_info": {"resolution": [int(cols), int(rows)], "depth_shape": list(depth_shape)},
+        "camera_info": {"intrinsic": tensor_to_json_serializable(K), "extrinsic": tensor_to_json_serializable(E)},
+        "gaussian_params": fitted,
+        "num_objects": len(fitted),
+        "obj_id_to_color_idx": colour_of,
     }
-    with open(output_path / "gaussian_params.json", "w") as f:
-        json.dump(output_data, f, indent=2)
-    logger.info(f"Saved parameters to {output_path / 'gaussian_params.json'}")
-    return output_data
+    with open(out_dir / "gaussian_params.json", "w") as fh:
+        json.dump(result, fh, indent=2)
+    logger.info(f"{out_dir / 'gaussian_params.json'}: {len(fitted)} objects")
+    return result
 
 
 def parse_args(argv=None):
