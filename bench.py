@@ -36,6 +36,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_FP8_TFLOPS = 5000.0     # dense fp8 MFMA peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 WORKLOADS = {
@@ -127,6 +128,16 @@ def cpu_baseline(mk, f_step, L):
             "host_cpus": os.cpu_count()}
 
 
+def dtype_label(args):
+    """`dtype` of the JSON line: the arithmetic type(s) the step computes in.  Anything but "bf16" is an opt-in mode, never the headline."""
+    lin, att = args.fp8_linear, args.fp8_attn >= 0
+    if not lin and not att:
+        return "bf16"
+    parts = ["fp8 e4m3 linear layers (per-token x per-channel scales, fp32 accumulate)" if lin else "bf16 linear layers",
+             (f"fp8 e4m3 self-attention (MX block scales, pmode {args.fp8_attn})" if att else "bf16 attention")]
+    return " + ".join(parts) + ": NOT the bf16 headline"
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +149,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cfg-degree", type=int, default=int(os.environ.get("VC_BENCH_CFG_DEGREE", "0")), choices=(0, 1, 2),
                     help="ranks that split the CFG pair (0 = auto: 2 when --gpus 2, else 1)")
+    ap.add_argument("--fp8-attn", type=int, default=-1, choices=(-1, 0, 1),
+                    help="run the blocks' SELF-attention in fp8 (q, k, v and the softmax weights e4m3 under MX-style block scales; NOT the "
+                         "headline): 1 = the weights' bytes from the piecewise-linear 2^x, 0 = v_exp_f32; -1 (default) = bf16 attention")
     ap.add_argument("--fp8-linear", action="store_true",
                     help="run the blocks' nn.Linear layers in fp8 (BASELINE config 5's dtype; NOT the headline: the reference computes in "
                          "bf16) -- the line then says dtype 'fp8 e4m3 linear layers (fp32 accumulate) + bf16 attention'")
@@ -487,6 +501,8 @@ def run_rank(args):
     model.init_weights(zero_init_outputs=False)
     if args.fp8_linear:
         model.enable_fp8_linear()
+    if args.fp8_attn >= 0:
+        model.enable_fp8_attention(True, args.fp8_attn)
     scheduler = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
     pipe = WanVerseCrafterPipeline(transformer=model, scheduler=scheduler)
     pipe._guidance_scale = 5.0
@@ -598,7 +614,7 @@ def run_rank(args):
                       else f"denoise-steps/sec {args.workload}",
             "value": sps, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "fp8 e4m3 linear layers (fp32 accumulate) + bf16 attention: NOT the bf16 headline" if args.fp8_linear else "bf16", "data": "synthetic (random weights seed 0, inputs seed 2025)",
+            "vs_baseline": None, "dtype": dtype_label(args), "data": "synthetic (random weights seed 0, inputs seed 2025)",
             "config": {"workload": args.workload, "latent": [16, T, h, w], "tokens": L, "global_batch": 2,
                        "cfg": head["cfg"], "guidance_scale": 5.0, "sampler": "UniPC shift 16",
                        "teacache": "off", "parallelism": head["parallelism"], "pflop_per_step": f_step / 1e15},
@@ -635,9 +651,24 @@ def run_rank(args):
                     traffic_src = tj.get("source")
             except (OSError, ValueError):
                 pass
+            # fp8 modes: the dominant kernel is priced against the dense fp8 peak when it runs in fp8, and the whole step against the
+            # MIXED roofline -- time the step's fp8 FLOPs need at the fp8 peak plus its bf16 FLOPs at the bf16 peak (the class shares of
+            # the live profile applied to the algorithmic count) -- never against the bf16 peak alone
+            fp8_cls = {"gemm": args.fp8_linear, "attn_self": args.fp8_attn >= 0}
+            peak = PEAK_FP8_TFLOPS if fp8_cls.get(dom) else PEAK_BF16_TFLOPS
+            if fp8_cls.get(dom):
+                kname = {"attn_self": "attn_fp8_kernel", "gemm": "gemm_pp_kernel<FP8>"}[dom]
+                traffic, traffic_src = None, None
+            if any(fp8_cls.values()):
+                tot = sum(vv["flops"] for vv in prof.values()) or 1.0
+                f8 = sum(prof[c]["flops"] for c, on in fp8_cls.items() if on) / tot * f_step
+                t_roof = f8 / (PEAK_FP8_TFLOPS * 1e12) + (f_step - f8) / (PEAK_BF16_TFLOPS * 1e12)
+                out["step_mixed_roofline_frac"] = t_roof * sps / world
+                out["step_mfma_frac_note"] = ("step_mfma_frac divides by the bf16 peak and is NOT a roofline fraction of this mode; "
+                                              "step_mixed_roofline_frac prices the fp8 classes at 5 PF and the rest at 2.5 PF")
             out["roofline"] = {"bound": "mfma", "kernel": kname,
-                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic,
                                "traffic_source": (f"recorded, not live: {traffic_src}" if traffic is not None else None),
                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
             if world > 1:

@@ -165,6 +165,13 @@ int vc_time_embedding(vc_engine* h, const float* t, int B, float* e0_out, void* 
 int vc_profile_enable(vc_engine* h, int on);
 int vc_profile_read(vc_engine* h, int ncls, int64_t* count, double* ms, double* flops, double* bytes);
 
+/* A new video through the same handle: forget the stored TeaCache residuals (TeaCache.reset() of the third-party class clears
+ * previous_residual_cond / _uncond; here they live in the engine).  The slots stay allocated; VC_FWD_USE_RESIDUAL before the next
+ * VC_FWD_STORE_RESIDUAL fails with VC_E_STATE instead of re-adding the previous video's residual. */
+int vc_reset_residuals(vc_engine* h);
+/* forwards served by a hipGraph replay since vc_create (small token counts; tests assert that a replay really happened) */
+int64_t vc_graph_replays(const vc_engine* h);
+
 /* bytes of library-owned device workspace currently allocated */
 int64_t vc_workspace_bytes(const vc_engine* h);
 
@@ -188,6 +195,19 @@ int vc_op_attention(const void* q, const void* k, const void* v, void* out, int 
 int vc_op_attention_variant(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                             const int64_t* o_strides, int k_len, float scale, int variant, void* stream);
+
+/* fp8 self-attention (this build; BASELINE config 5 names "fp8 MFMA" -- the reference computes attention in bf16 through flash-attn,
+ * WT.py:394-399).  Same contract as vc_op_attention for the bf16 inputs and the bf16 output; inside, q, k, v AND the softmax weights are
+ * OCP e4m3 with one E8M0 power-of-two scale per 32 elements along each contraction (MX-style), both products run on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation (csrc/attention_fp8.hip; CPU restatement oracle/attn_fp8_oracle.py).
+ *   pmode 1: the e4m3 byte of a weight is round(8 log2 w + 56), i.e. the piecewise-linear 2^x -- no exponential; pmode 0: v_exp_f32.
+ *   stage 0: quantise + attend; 1: quantise q / k / v into the workspace only; 2: attend on a workspace stage 1 filled (same shape).
+ *   workspace: 256-byte aligned device memory of >= vc_op_attention_fp8_workspace_bytes(B, H, Lq, Lk) bytes.
+ * PARITY: "within the fp8 error of exact attention" (bounds in tests/test_gpu_attention_fp8.py); the definition itself is pinned. */
+int64_t vc_op_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk);
+int vc_op_attention_fp8(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk, const int64_t* q_strides,
+                        const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, int k_len, float scale, int pmode,
+                        int stage, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Ring attention building blocks (the ring half of the reference's Ulysses x ring hybrid, third-party xFuserLongContextAttention bound at
  * WT.py:907-921; CLI.py:59-62): attention over ONE block of keys that also returns, per query row, the log2-domain log-sum-exp of its
@@ -393,6 +413,12 @@ int vc_op_h264_pcm_unpack(const void* in, void* rgb, int frames, int H, int W, v
  *                             text K/V and the head stay bf16.  on == 0 frees the copies.  vc_fp8_linear: 1 when the mode is on.        */
 int vc_set_fp8_linear(vc_engine* h, int on);
 int vc_fp8_linear(const vc_engine* h);
+/*   vc_set_fp8_attention      engine mode: on != 0 runs the SELF-attention of the main and adapter blocks through vc_op_attention_fp8's kernels
+ *                             (q, k, v and the softmax weights in e4m3 under MX-style block scales; pmode as there); takes effect at the next
+ *                             vc_prepare_video, which then reserves the quantised operands' workspace in the arena.  Cross-attention and the
+ *                             Ulysses x ring hybrid's per-block attention stay bf16.  vc_fp8_attention: 1 when the mode is on.        */
+int vc_set_fp8_attention(vc_engine* h, int on, int pmode);
+int vc_fp8_attention(const vc_engine* h);
 int vc_op_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, void* scale, int M, int K, void* stream);
 int vc_op_gemm_fp8(const void* A, int64_t lda, const void* a_scale, const void* W, int64_t ldw, const void* w_scale, void* C, int64_t ldc,
                    const void* bias, int M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate,

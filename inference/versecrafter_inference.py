@@ -52,6 +52,10 @@ def parse_args(argv=None):
     p.add_argument("--cfg_degree", type=int, default=1, choices=(1, 2),
                    help="(this build) ranks that split the classifier-free-guidance pair: world = cfg_degree * ulysses_degree * "
                         "ring_degree; with 2 GPUs, `--cfg_degree 2 --ulysses_degree 1 --ring_degree 1` needs no sequence exchange")
+    p.add_argument("--sp_layout", type=str, default="auto", choices=("auto", "as_given"),
+                   help="(this build) auto: ulysses_degree x ring_degree runs as pure Ulysses of the product wherever the head count divides "
+                        "by it (14B: 40 heads), else as the hybrid; as_given: exactly the U x R of the flags (the reference's documented "
+                        "layout, inference.sh:62-71), e.g. to time 2 x 4 against Ulysses-8 on hardware")
     p.add_argument("--guidance_scale", type=float, default=5.0)
     p.add_argument("--seed", type=int, default=2025)
     p.add_argument("--fps", type=int, default=16)
@@ -92,6 +96,10 @@ def parse_args(argv=None):
                    help="(this build; BASELINE config 5 names fp8 MFMA) 1: the blocks' nn.Linear layers run in fp8 (e4m3 weights per output "
                         "channel, activations per token, fp32 accumulation); attention and everything else stay bf16.  The reference "
                         "computes in bf16: results then differ from it by the quantisation error")
+    p.add_argument("--fp8_attention", type=int, default=-1, choices=(-1, 0, 1),
+                   help="(this build; BASELINE config 5 names fp8 MFMA) 1 / 0: the blocks' SELF-attention runs in fp8 -- q, k, v and the softmax "
+                        "weights as e4m3 under one power-of-two scale per 32 elements, both products on the block-scaled MFMA; 1 makes the weights' "
+                        "bytes from the piecewise-linear 2^x, 0 from v_exp_f32.  -1 (default): bf16 attention, as the reference")
     p.add_argument("--synthetic_high_noise_expert", action="store_true",
                    help="with --synthetic_model: a second random model (seed 1) as the high-noise expert")
     p.add_argument("--control_latents_path", type=str, default=None,
@@ -103,7 +111,8 @@ def parse_args(argv=None):
 def main(argv=None):
     args = parse_args(argv)
     height, width = [int(x) for x in args.sample_size.split(",")]
-    device = set_multi_gpus_devices(args.ulysses_degree, args.ring_degree, cfg_degree=args.cfg_degree)
+    device = set_multi_gpus_devices(args.ulysses_degree, args.ring_degree, cfg_degree=args.cfg_degree,
+                                    ring_as_given=args.sp_layout == "as_given")
     if device.type != "cuda":
         raise SystemExit("versecrafter_amd needs an MI355X (HIP) device: there is no CPU path")
     weight_dtype = torch.bfloat16
@@ -171,6 +180,8 @@ def main(argv=None):
     for m in experts:
         if args.fp8_linear:
             m.enable_fp8_linear()
+        if args.fp8_attention >= 0:
+            m.enable_fp8_attention(True, args.fp8_attention)
         if args.enable_teacache:                                                    # CLI.py:305-313
             m.enable_teacache(TEACACHE_COEFFICIENTS_14B, args.num_inference_steps, args.teacache_threshold,
                               num_skip_start_steps=args.num_skip_start_steps, offload=False)

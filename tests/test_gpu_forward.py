@@ -361,15 +361,15 @@ def test_cli_runs_end_to_end(tmp_path):
     assert torch.isfinite(q).all() and 1e-4 < drift < 0.25, drift
 
 
-@pytest.mark.parametrize("name,dims,grid", [
+@pytest.mark.parametrize("name,dims,grid,e_ref_recorded", [
     # BASELINE.json config 1 geometry (1.3B width: d=1536, 12 heads, ffn 8960; 9 frames 320x512 -> latent [16,3,40,64],
     # 1920 tokens) with the depth cut to 4+2 blocks so that the CPU oracle finishes in seconds
-    ("wan1.3b-width", dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=4), (3, 40, 64)),
+    ("wan1.3b-width", dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=4), (3, 40, 64), 0.007611),
     # 14B width (d=5120, 40 heads, ffn 13824, text 512 x 4096) on a short clip: every kernel at its production shape in
     # the channel dimension (10-chunk row kernels, N=13824 GEMM, 40-head attention, 512-key cross attention)
-    ("wan14b-width", dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=2), (2, 16, 24)),
+    ("wan14b-width", dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=2), (2, 16, 24), 0.006594),
 ])
-def test_forward_production_widths_vs_oracle(name, dims, grid):
+def test_forward_production_widths_vs_oracle(name, dims, grid, e_ref_recorded):
     from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
     cfgk = dict(dims, geoada_in_dim=128, in_dim=16, out_dim=16, text_dim=4096, text_len=512, freq_dim=256)
     cfg = O.Config(**cfgk)
@@ -404,12 +404,14 @@ def test_forward_production_widths_vs_oracle(name, dims, grid):
     args = (Wf, cfg, x.float(), t, geo.float(), [c.float() for c in ctx], L)
     want = O.forward(*args)
     e_hip = rel(got, want)
-    # the oracle's own bf16-rounding mode on these seeded inputs: 0.01444 (recorded; a second full-depth CPU forward costs 85 s of the
-    # suite -- VC_TEST_RECOMPUTE_BF16_REF=1 recomputes it)
-    e_ref = rel(O.forward(*args, mode="bf16"), want) if os.environ.get("VC_TEST_RECOMPUTE_BF16_REF") == "1" else 0.01444
+    # the oracle's own bf16-rounding mode on THESE seeded inputs, one constant per case (recorded with the oracle in this repo: 8.5 s
+    # and 1.6 s of CPU each; VC_TEST_RECOMPUTE_BF16_REF=1 recomputes them).  Round 3 had put the 45-block cfg-1 figure (0.01444) here,
+    # which made the 3x clause looser than the absolute bound; with the cases' own figures it binds again: 0.0248 / 0.0218 < 3e-2.
+    e_ref = rel(O.forward(*args, mode="bf16"), want) if os.environ.get("VC_TEST_RECOMPUTE_BF16_REF") == "1" else e_ref_recorded
     print(f"{name}: engine rel L2 {e_hip:.4g}; bf16-reference rel L2 {e_ref:.4g}")
     assert torch.isfinite(got.float()).all()
-    assert e_hip < 3e-2 and e_hip < 3 * e_ref + 2e-3
+    assert 3 * e_ref + 2e-3 < 3e-2                    # the clause below is the binding one
+    assert e_hip < 3 * e_ref + 2e-3
     del m
     torch.cuda.empty_cache()
 
@@ -499,17 +501,74 @@ def wan14b():
     torch.cuda.empty_cache()
 
 
-def test_two_resident_14b_experts_switch_at_the_boundary(wan14b):
+@pytest.fixture(scope="module")
+def wan14b_high():
+    """The HIGH-noise expert of a Wan2.2-style pair: a second Wan-14B + GeoAdapter (another 43.7 GB), built once."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    m = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16,
+                                          dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, skip_init=True)
+    m.init_weights(zero_init_outputs=False)
+    yield m
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_config5_two_experts_fp8_at_81_frames_720p(wan14b, wan14b_high):
+    """BASELINE config 5 at ITS workload on one GPU: the Wan2.2-style pair (two resident 14B + GeoAdapter experts switched at `boundary`),
+    fp8 linear layers AND fp8 self-attention, latent [16, 21, 90, 160] = 81 frames 1280 x 720, L = 75 600, the CFG pair batched.  The
+    reference has no code for this configuration (config/wan2.2/wan_civitai_t2v.yaml:4-7 is read by nothing) and sizes like this are out
+    of the CPU oracle's reach: size-independent properties -- both experts run (one sampler step on each side of the boundary), finite,
+    the two CFG halves are computed independently (swapping the prompts swaps the outputs bit for bit, which is also determinism), and the
+    fp8 forward stays within the drift bound test_fp8_linear_mode / test_fp8_attention_mode state against the bf16 forward."""
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    low, high, dev = wan14b, wan14b_high, torch.device("cuda", 0)
+    T, h, w = 21, 90, 160
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(1, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
+    geo = torch.randn(1, 128, T, h, w, generator=g).to(dev, torch.bfloat16)
+    pe, ne = torch.randn(77, 4096, generator=g).to(dev, torch.bfloat16), torch.randn(60, 4096, generator=g).to(dev, torch.bfloat16)
+    L = T * (h // 2) * (w // 2)
+    assert L == 75600
+    x2, geo2, t = torch.cat([x, x]), torch.cat([geo, geo]), torch.tensor([900.0, 900.0], device=dev)
+    ref = low(x2, t, geo2, [ne, pe], L).clone()                                   # bf16
+    try:
+        for m in (low, high):
+            m.enable_fp8_linear()
+            m.enable_fp8_attention(True, 1)
+        a = low(x2, t, geo2, [ne, pe], L).clone()
+        b = low(x2, t, geo2, [pe, ne], L)
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a[0], b[1]) and torch.equal(a[1], b[0])
+        e = rel(a, ref)
+        print(f"config 5 clip, fp8 linear + fp8 self-attention vs bf16 on the low-noise expert: rel L2 {e:.4g}")
+        assert 1e-3 < e < 0.2, e
+        # the pair through the sampler: two steps, one on each side of the boundary (shift 1: t = 1000, 500)
+        pipe = WanVerseCrafterPipeline(transformer=low, transformer_2=high, scheduler=FlowUniPCMultistepScheduler(shift=1))
+        out = pipe(prompt_embeds=[pe], negative_prompt_embeds=[ne], height=h * 8, width=w * 8, geoada_latents=[geo[0, :64]],
+                   mask_latents=[geo[0, 64:]], num_inference_steps=2, guidance_scale=5.0, shift=1, latents=x.clone(), output_type="latent",
+                   boundary=0.875).videos
+        torch.cuda.synchronize()
+        assert pipe._high_noise_steps == [True, False]
+        assert out.shape == (1, 16, T, h, w) and torch.isfinite(out.float()).all()
+        free, total = torch.cuda.mem_get_info()
+        print(f"config 5 at 81 x 720 x 1280, two resident experts, fp8: {(total - free) / 2**30:.1f} GiB of {total / 2**30:.0f} GiB in use")
+    finally:
+        for m in (low, high):
+            m.enable_fp8_linear(False)
+            m.enable_fp8_attention(False)
+    assert torch.equal(low(x2, t, geo2, [ne, pe], L), ref)                         # the modes switch off cleanly
+
+
+def test_two_resident_14b_experts_switch_at_the_boundary(wan14b, wan14b_high):
     """BASELINE config 5's model pair at full size: two Wan-14B + GeoAdapter experts (2 x 43.7 GB of weights) resident on ONE MI355X,
     a four-step sampler that crosses the boundary; the result equals the single-expert pipelines swapped by hand at the switch."""
-    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
     from versecrafter_amd.pipeline import WanVerseCrafterPipeline
     from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
     dev = torch.device("cuda", 0)
-    torch.manual_seed(1)
-    high = VerseCrafterWanTransformer3DModel(geoada_in_dim=128, param_device=dev, param_dtype=torch.bfloat16,
-                                             dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, skip_init=True)
-    high.init_weights(zero_init_outputs=False)
+    high = wan14b_high
     g = torch.Generator().manual_seed(9)
     T, h, w = 2, 16, 24
     lat0 = torch.randn(1, 16, T, h, w, generator=g).to(dev, torch.bfloat16)
@@ -536,8 +595,6 @@ def test_two_resident_14b_experts_switch_at_the_boundary(wan14b):
     free, total = torch.cuda.mem_get_info()
     print(f"two resident 14B experts: {(total - free) / 2**30:.1f} GiB of {total / 2**30:.0f} GiB in use")
     assert total - free > 80 * 2**30                          # both sets of weights are on the device
-    del high
-    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("name,T,h,w", [
@@ -797,7 +854,10 @@ def test_fp8_layernorm_fusion_is_bit_equal_to_the_separate_quantiser(width, monk
         m.init_weights(zero_init_outputs=False)
         m.enable_fp8_linear()
         outs.append(m(x, t, geo, ctx, L).clone())
-        outs.append(m(x, t, geo, ctx, L).clone())                    # second call: graph replay where the model is small enough
+        outs.append(m(x, t, geo, ctx, L).clone())                    # second call: captured and replayed (M <= 16384 rows)
+        # the capture really happened: in fp8 mode the capture stream's scratch exists before the capture begins (round-3 advisor finding:
+        # it used to be allocated INSIDE the capture, the capture was dropped silently and every forward stayed eager)
+        assert m.graph_replays() >= 1
         del m
         torch.cuda.empty_cache()
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 1e-3

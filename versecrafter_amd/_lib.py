@@ -71,6 +71,8 @@ SYMBOLS = {
     "vc_forward": (_I, [_P, _P, _P, _P, _F, C.c_uint32, _P]),
     "vc_time_embedding": (_I, [_P, _P, _I, _P, _P]),
     "vc_workspace_bytes": (_L, [_P]),
+    "vc_reset_residuals": (_I, [_P]),
+    "vc_graph_replays": (_L, [_P]),
     "vc_profile_enable": (_I, [_P, _I]),
     "vc_profile_read": (_I, [_P, _I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double),
                              C.POINTER(C.c_double)]),
@@ -79,6 +81,9 @@ SYMBOLS = {
                              C.POINTER(_L), _I, _F, _P]),
     "vc_op_attention_variant": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
                                      C.POINTER(_L), _I, _F, _I, _P]),
+    "vc_op_attention_fp8_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "vc_op_attention_fp8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _F, _I, _I,
+                                 _P, _L, _P]),
     "vc_op_attention_lse": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _F, _P]),
     "vc_op_attention_merge": (_I, [C.POINTER(_P), C.POINTER(_P), _I, _P, _I, _I, _I, C.POINTER(_L), _P]),
     "vc_op_attention_segmented": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L),
@@ -93,6 +98,8 @@ SYMBOLS = {
     "vc_op_render_blend": (_I, [_P, _P, _P, _P, _L, _I, _P]),
     "vc_set_fp8_linear": (_I, [_P, _I]),
     "vc_fp8_linear": (_I, [_P]),
+    "vc_set_fp8_attention": (_I, [_P, _I, _I]),
+    "vc_fp8_attention": (_I, [_P]),
     "vc_op_quantize_rows_fp8": (_I, [_P, _L, _P, _L, _P, _I, _I, _P]),
     "vc_op_gemm_fp8": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _I, _P]),
     "vc_h264_pcm_last_error": (C.c_char_p, []),

@@ -436,7 +436,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_row < p.Lq) {
+    // Epilogue (round 4: the widened store tail of attn_short_kernel, cdna_hip_programming.md T21): a lane holds 8-byte pieces (4 dims)
+    // at dims db*32 + 8*g4 + 4*h and lane r + 32 holds the neighbouring pieces of the same row; one permlane32 swap per register pairs
+    // them up so that every lane stores 16 contiguous bytes -- 8 dwordx4 instead of 16 dwordx2 (the row-per-lane store tail is
+    // issue-bound).  Rows whose stride is not a multiple of 16 bytes keep the 8-byte form.
+    const bool wide = (((p.o_ts | p.o_hs | p.o_bs | p.o_ss) & 7) == 0) && (((uintptr_t)p.out & 15) == 0);
+    const int q_row_s = q_row < p.Lq ? q_row : p.Lq - 1;
+    if (wide) {
+        bf16_t* orow = op + tok_off<SEG>(q_row_s, p.o_ts, p.seg_len, p.o_ss) + 8 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float va[4], vb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = O[db][8 * j + e] * inv; vb[e] = O[db][8 * j + 4 + e] * inv; }
+                const uint2 pa = pack4(va), pb = pack4(vb);       // g4 = 2j and g4 = 2j + 1 of this half
+                const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                // lanes 0-31: {own 2j, partner's 2j}; lanes 32-63: {partner's 2j+1, own 2j+1}
+                if (q_row < p.Lq) *(uint4*)(orow + db * 32 + 16 * j) = uint4{sx[0], sy[0], sx[1], sy[1]};
+            }
+    } else if (q_row < p.Lq) {
         bf16_t* orow = op + tok_off<SEG>(q_row, p.o_ts, p.seg_len, p.o_ss) + 4 * h;
 #pragma unroll
         for (int db = 0; db < 4; ++db)

@@ -1,0 +1,547 @@
+// fp8 self-attention for gfx950 (round 4; BASELINE config 5 names "fp8 MFMA" -- an opt-in mode of this build, the reference computes
+// attention in bf16 through flash-attn, wan_transformer3d.py:394-399):  out = softmax(q k^T / sqrt(D)) v, head dim 128, non-causal,
+// keys >= k_len masked, with Q, K, V AND the softmax weights P held as OCP e4m3 under MX-style block scales (one E8M0 power of two per
+// 32 elements along the contraction), both products on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation.
+//
+// Two kernels:
+//  1. attn_quant_fp8_kernel: one pass over the bf16 q / k / v of a (batch, head, 64-token tile) that writes
+//       Q8  [B][H][tile][64][128]  e4m3, natural d order, pre-multiplied by scale * log2(e) * 8 / 65535 (the softmax constant and the
+//                                  byte mapping of P below are folded into Q before it is quantised); Qs [..][64][4] scale bytes
+//       K8  [B][H][tile][9216]     the LDS IMAGE of the tile: 64 rows of 128 B at a pitch of 144 B (9 sixteen-byte slots: the 16 lanes of a
+//                                  ds_read_b128 group then fall on 16 different slots of the 256-byte bank row with NO xor swizzle, so a
+//                                  lane's two chunks stay adjacent and land in one 8-register tuple without moves); Ks [..][256]
+//       V8  [B][H][tile][10240]    V TRANSPOSED: 128 rows (d) of 64 B at a pitch of 80 B, the 64 keys of the tile in the order the P
+//                                  fragment holds them (below); Vs [..][256]
+//     so the attention kernel's LDS-DMA is a linear copy of whole images and no transposed LDS read is needed.
+//     Scale blocks follow the MFMA: the instruction's k-block b (32 of its 64 k) is bytes 16b .. 16b+15 of BOTH lane halves, and the
+//     scale of (row, block b) is supplied by lane 32 b + row (probed: tools/micro/fp8_attn_probe.hip).  A lane reads 32 contiguous bytes
+//     (2s+h)*32.. of its q / k row for k-step s, so block (s, b) of a q / k row is d in {64s+16b .. +15} u {64s+32+16b .. +15}; a block
+//     of V^T is one d column over the 32 keys kb*32 .. kb*32+31.  A block's scale is the smallest power of two 2^e with amax <= 448 2^e
+//     (no saturation: v_cvt_pk_fp8_f32 turns values >= 480 into NaN); elements are rounded to nearest even.
+//  2. attn_fp8_kernel: the structure of attn_fwd_pipe_kernel (8 waves x 32 query rows, 64-key tiles, S^T = K Q^T with the query on the
+//     lane, O^T += V^T P^T, software pipeline MFMA(S(t+1)) || VALU(P(t)), MFMA(PV(t)) || VALU(max(t+1)), deferred rescale) with
+//       * 4 + 4 MFMAs per tile instead of 16 + 16, half the LDS bytes, K / V / scales through a 4-deep LDS ring filled two tiles
+//         ahead by LDS-DMA behind a counted vmcnt(2) and a raw s_barrier;
+//       * P per (row, tile) block-scaled: e = ceil(log2 of the tile's largest weight relative to the row's reference), P 2^(8-e) in
+//         e4m3 (largest byte in (112, 120]), the block scale 2^(e-8) goes into the MFMA's scale operand -- a tile far below the running
+//         maximum keeps full relative precision instead of flushing to zero;
+//       * the row sum comes from a ninth MFMA against an all-ones A operand: l is the sum of exactly the P values the PV product saw;
+//       * PMODE 1 ("log-domain", default): P's byte is produced WITHOUT an exponential: byte = round(8 log2(P 2^(8-e)) + 56) is an e4m3
+//         bit pattern whose value is 2^floor(.) (1 + frac / 8) -- the piecewise-linear 2^x, at most 6.1 % above the exponential and
+//         identical for numerator and denominator; with the constants folded into Q it is one v_add_f32 per element plus 2
+//         v_cvt_pknorm_u16_f32 + 1 v_perm_b32 per four (the fp8 loop is VALU-bound: tools/micro/fp8_attn_probe*.hip);
+//         PMODE 0 ("exact"): v_exp_f32 and v_cvt_pk_fp8_f32.
+// Restated on the CPU in oracle/attn_fp8_oracle.py (the definition the tests pin; parity with the reference is "within the fp8 error
+// of exact attention", bounds in tests/test_gpu_attention_fp8.py).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "vc_common.h"
+#include "vc_kernels.h"
+
+namespace {
+
+constexpr int KT = 64;
+constexpr int KPITCH = 144, VPITCH = 80;          // row pitch of the K / V^T tile images (128 / 64 data bytes + 16 of padding)
+constexpr int KTILE = KT * KPITCH, VTILE = 128 * VPITCH, STILE = 256;      // bytes of a K image (9 KiB), a V^T image (10 KiB), a scale tile
+constexpr int NST = 4;                            // LDS ring depth
+constexpr int F8_KST = 0, F8_VST = NST * KTILE, F8_KSC = F8_VST + NST * VTILE, F8_VSC = F8_KSC + NST * STILE;
+constexpr int F8_LDS = F8_VSC + NST * STILE;      // 78 KiB
+typedef i32x8 __attribute__((aligned(16))) i32x8_a16;
+constexpr float K1 = 65535.0f / 8.0f;             // raw accumulator units -> log2 units
+constexpr float DEFER_T = 8.0f;                   // a row's reference follows its maximum once it is 2^8 behind (as the bf16 kernel)
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+
+// smallest e with amax <= 448 * 2^e, as the E8M0 byte e + 127 clamped to [0, 254]  (448 = 1.75 * 2^8)
+VC_DEVICE int mx_scale_byte(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    const int E = (int)((u >> 23) & 0xFFu);
+    int sb = E - 8 + ((u & 0x7FFFFFu) > 0x600000u ? 1 : 0);
+    sb = sb < 0 ? 0 : sb;
+    return sb > 254 ? 254 : sb;
+}
+VC_DEVICE float mx_inv_scale(int sb) { return __uint_as_float((unsigned)(254 - sb) << 23); }     // 2^(127 - sb)
+
+// 16 floats (already multiplied by the block's inverse scale) -> 16 e4m3 bytes, element j in byte j
+VC_DEVICE uint4 cvt16_fp8(const float (&x)[16]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * i], x[4 * i + 1], 0, false);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * i + 2], x[4 * i + 3], r, true);
+        w[i] = (unsigned)r;
+    }
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// quantiser: one workgroup of 256 threads per (batch, head, 64-token tile)
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, int nTq, int nTk, int ntile) {
+    const int tile = blockIdx.x % ntile, bh = blockIdx.x / ntile;
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int tid = threadIdx.x;
+    const bf16_t* qp = (const bf16_t*)p.q + (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+    const bf16_t* kp = (const bf16_t*)p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+    const bf16_t* vp = (const bf16_t*)p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+    char* ws = (char*)p.ws;
+    const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;      // keys past it are quantised as zeros: they never reach a sum
+    // ---- q and k rows: thread = (token r, block (s, bb)) ----
+    {
+        const int r = tid >> 2, blk = tid & 3, s = blk >> 1, bb = blk & 1;
+        const int d0 = 64 * s + 16 * bb, d1 = d0 + 32;
+        const int tok = tile * KT + r;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {           // 0: q, 1: k
+            const bool isq = which == 0;
+            const int L = isq ? p.Lq : k_len, nT = isq ? nTq : nTk;
+            if (tile >= nT) continue;
+            float x[32];
+            if (tok < L) {
+                const bf16_t* row = (isq ? qp + (int64_t)tok * p.q_ts : kp + (int64_t)tok * p.k_ts);
+                const uint4 a0 = *(const uint4*)(row + d0), a1 = *(const uint4*)(row + d0 + 8);
+                const uint4 c0 = *(const uint4*)(row + d1), c1 = *(const uint4*)(row + d1 + 8);
+                float t8[8];
+                unpack8(a0, t8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = t8[i];
+                unpack8(a1, t8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[8 + i] = t8[i];
+                unpack8(c0, t8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[16 + i] = t8[i];
+                unpack8(c1, t8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[24 + i] = t8[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) x[i] = 0.f;
+            }
+            if (isq) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) x[i] *= p.qfold;             // softmax constant and byte mapping folded into Q
+            }
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(x[i]));
+            const int sb = mx_scale_byte(amax);
+            const float inv = mx_inv_scale(sb);
+            float lo[16], hi[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { lo[i] = x[i] * inv; hi[i] = x[16 + i] * inv; }
+            const uint4 qlo = cvt16_fp8(lo), qhi = cvt16_fp8(hi);
+            if (isq) {
+                char* q8 = ws + p.off_q8 + ((int64_t)bh * nTq + tile) * (KT * 128) + r * 128;
+                *(uint4*)(q8 + d0) = qlo;
+                *(uint4*)(q8 + d1) = qhi;
+                (ws + p.off_qs + ((int64_t)bh * nTq + tile) * (KT * 4))[r * 4 + 2 * s + bb] = (char)sb;
+            } else {
+                char* k8 = ws + p.off_k8 + ((int64_t)bh * nTk + tile) * KTILE + r * KPITCH;
+                *(uint4*)(k8 + d0) = qlo;
+                *(uint4*)(k8 + d1) = qhi;
+                if (blk == 0) *(uint4*)(k8 + 128) = uint4{0u, 0u, 0u, 0u};          // the pad travels with the image: keep it defined
+                (ws + p.off_ks + ((int64_t)bh * nTk + tile) * STILE)[(bb * 32 + (r & 31)) * 4 + (r >> 5) * 2 + s] = (char)sb;
+            }
+        }
+    }
+    // ---- v: thread = (column d, key block kb) ----
+    if (tile < nTk) {
+        const int d = tid & 127, kb = tid >> 7;
+        float x[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int key = tile * KT + kb * 32 + i;
+            x[i] = key < k_len ? (float)vp[(int64_t)key * p.v_ts + d] : 0.f;
+            amax = fmaxf(amax, fabsf(x[i]));
+        }
+        const int sb = mx_scale_byte(amax);
+        const float inv = mx_inv_scale(sb);
+        char* v8 = ws + p.off_v8 + ((int64_t)bh * nTk + tile) * VTILE + d * VPITCH;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) y[j] = x[(j & 3) + 8 * (j >> 2) + 4 * hh] * inv;     // the key order of the P fragment
+            *(uint4*)(v8 + 32 * hh + 16 * kb) = cvt16_fp8(y);
+        }
+        if (kb == 0) *(uint4*)(v8 + 64) = uint4{0u, 0u, 0u, 0u};
+        (ws + p.off_vs + ((int64_t)bh * nTk + tile) * STILE)[(kb * 32 + (d & 31)) * 4 + (d >> 5)] = (char)sb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------------------------------------------
+VC_DEVICE void f8_glds16(unsigned voff, const void* sbase, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst_uniform)
+                 : "memory");
+}
+VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+// The scaled MFMA is issued by inline asm with the accumulator TIED (through the builtin hipcc, ROCm 7.2, leaves vdst != srcC for part
+// of them: the accumulators migrate between tuples and ~260 VGPRs spill into the loop -- the round-3 finding of the fp8 GEMM again).
+// What hipcc then no longer does for these instructions is done by hand:
+//   * operands that a VALU instruction may just have written (the P fragment, its scale): `s_nop 1` in front of the first MFMA of the group;
+//   * an accumulator is read by VALU code only behind F8_MFMA_SETTLE (20 wait states for a 16-pass MFMA) or behind a later group of
+//     MFMAs of the same wave (the matrix pipe is in order);
+//   * ds_read results feeding an asm operand are waited for by the compiler's own lgkmcnt pass.
+// OPS: op_sel / op_sel_hi select the scale BYTE of the two scale registers (x = a's byte, y = b's byte: op_sel:[x&1,y&1,0] op_sel_hi:[x>>1,y>>1,0]).
+#define F8_OPS_00 "op_sel_hi:[0,0,0]"
+#define F8_OPS_10 "op_sel:[1,0,0] op_sel_hi:[0,0,0]"
+#define F8_OPS_20 "op_sel:[0,0,0] op_sel_hi:[1,0,0]"
+#define F8_OPS_30 "op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define F8_OPS_12 "op_sel:[1,0,0] op_sel_hi:[0,1,0]"
+#define F8_OPS_32 "op_sel:[1,0,0] op_sel_hi:[1,1,0]"
+#ifndef F8_POST
+#define F8_POST ""
+#endif
+#ifndef F8_PRE
+#define F8_PRE "s_nop 1\n\t"
+#endif
+#define F8_MFMA(acc, a, b, sa, sb, OPS) \
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS F8_POST : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_NOP(acc, a, b, sa, sb, OPS) \
+    asm volatile(F8_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS F8_POST : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_ZERO(acc, a, b, sa, sb, OPS) \
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 " OPS F8_POST : "=&v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_ZERO_NOP(acc, a, b, sa, sb, OPS) \
+    asm volatile(F8_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 " OPS F8_POST : "=&v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_SETTLE4(a0, a1, a2, a3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
+
+template <int PMODE>
+__global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int nQ, int nwork, int nTq, int nTk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per_xcd = gridDim.x >> 3;
+    const int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (id >= nwork) return;
+    const int bh = id / nQ, qb = id - bh * nQ;
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    const char* ws = (const char*)p.ws;
+    const char* q8 = ws + p.off_q8 + (int64_t)bh * nTq * (KT * 128);
+    const char* qs = ws + p.off_qs + (int64_t)bh * nTq * (KT * 4);
+    const char* k8 = ws + p.off_k8 + (int64_t)bh * nTk * KTILE;
+    const char* ks = ws + p.off_ks + (int64_t)bh * nTk * STILE;
+    const char* v8 = ws + p.off_v8 + (int64_t)bh * nTk * VTILE;
+    const char* vs = ws + p.off_vs + (int64_t)bh * nTk * STILE;
+    bf16_t* op = (bf16_t*)p.out + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
+
+    const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
+    const int nt = (k_len + KT - 1) / KT;
+    const bool tail_partial = (k_len & (KT - 1)) != 0;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+    const unsigned lane16 = (unsigned)(wave * 1024 + lane * 16), lane4 = (unsigned)(lane * 4);
+
+    // One wave-instruction of LDS-DMA moves 1 KiB; a K image is 9 such pieces, a V^T image 10: wave w moves piece w of each, wave 0 also
+    // piece 8 of both, wave 1 piece 9 of V^T.  Loads of one loop iteration t (issued right after its barrier), in THIS order: the extras
+    // -- wave 0: K scales of tile t+2, piece 8 of K(t+3) and of V(t+2); wave 1: V scales of tile t+1, piece 9 of V(t+2) -- then EVERY
+    // wave's own piece of K(t+3) and of V(t+2).  At the top of the next iteration vmcnt(2) leaves only those last two in flight on every
+    // wave: scales have one iteration to land, tile images two.  Tiles past the last one are clamped (the slot they land in is free).
+    auto stage_k = [&](int tile, int slot, bool extras) {
+        const char* src = k8 + (int64_t)tile * KTILE;
+        const unsigned dst = lds0 + F8_KST + slot * KTILE;
+        if (extras) { if (wave == 0) f8_glds16(lane * 16, src + 8192, __builtin_amdgcn_readfirstlane(dst + 8192)); }
+        else f8_glds16(lane16, src, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
+    };
+    auto stage_v = [&](int tile, int slot, bool extras) {
+        const char* src = v8 + (int64_t)tile * VTILE;
+        const unsigned dst = lds0 + F8_VST + slot * VTILE;
+        if (extras) { if (wave < 2) f8_glds16(lane * 16, src + 8192 + wave * 1024, __builtin_amdgcn_readfirstlane(dst + 8192 + wave * 1024)); }
+        else f8_glds16(lane16, src, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
+    };
+    auto stage_ks = [&](int tile, int slot) {
+        if (wave == 0) f8_glds4(lane4, ks + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_KSC + slot * STILE));
+    };
+    auto stage_vs = [&](int tile, int slot) {
+        if (wave == 1) f8_glds4(lane4, vs + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_VSC + slot * STILE));
+    };
+    auto issue = [&](int t) {
+        const int tks = min(t + 2, nt - 1), tvs = min(t + 1, nt - 1), tk = min(t + 3, nt - 1), tv = min(t + 2, nt - 1);
+        stage_ks(tks, (t + 2) & 3);
+        stage_vs(tvs, (t + 1) & 3);
+        stage_k(tk, (t + 3) & 3, true);
+        stage_v(tv, (t + 2) & 3, true);
+        stage_k(tk, (t + 3) & 3, false);
+        stage_v(tv, (t + 2) & 3, false);
+    };
+    // ---- prologue loads: K(0), K(1), V(0) and the scales of K(0), K(1), V(0), drained once; then what "iteration -1" would have issued ----
+    {
+        const int t1 = min(1, nt - 1), t2 = min(2, nt - 1);
+        stage_ks(0, 0); stage_ks(t1, 1); stage_vs(0, 0);
+        stage_k(0, 0, true); stage_k(0, 0, false);
+        stage_k(t1, 1, true); stage_k(t1, 1, false);
+        stage_v(0, 0, true); stage_v(0, 0, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_k(t2, 2, true); stage_v(t1, 1, true);
+        stage_k(t2, 2, false); stage_v(t1, 1, false);
+    }
+
+    // ---- Q fragments and scales (registers for the whole kernel) ----
+    const int q_row = qb * 256 + wave * 32 + r;
+    const int q_row_c = q_row < p.Lq ? q_row : p.Lq - 1;
+    i32x8 qf[2];
+    int qsc;
+    {
+        const char* qrow = q8 + (int64_t)q_row_c * 128 + 32 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const i32x4 lo = *(const i32x4*)(qrow + 64 * s), hi = *(const i32x4*)(qrow + 64 * s + 16);
+            qf[s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        qsc = (int)((*(const unsigned*)(qs + (int64_t)q_row_c * 4)) >> (8 * h));      // byte 0: block (0, h), byte 2: block (1, h)
+    }
+    // fragment addresses: K row kb*32 + r, bytes (2s+h)*32 .. +31; V^T row db*32 + r, bytes 32h .. +31 (pitches 144 / 80: no swizzle)
+    const unsigned koff = (unsigned)(r * KPITCH + 32 * h), voff = (unsigned)(r * VPITCH + 32 * h);
+    i32x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = 0x38383838;             // e4m3 1.0
+    const int unit = 0x7F7F7F7F;
+
+    f32x16 O[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { O[0][e] = 0.f; O[1][e] = 0.f; O[2][e] = 0.f; O[3][e] = 0.f; }
+    float l_run = 0.f;
+    float m_run = -1e30f, m_new = -1e30f, m_tile = -1e30f;       // raw accumulator units (x K1 = log2 units)
+
+    auto qk = [&](int t, f32x16 (&S)[2]) {                        // S(t) = K(t) Q^T : 4 MFMAs
+        const char* kbuf = smem + F8_KST + (t & 3) * KTILE;
+        const int ksc = *(const int*)(smem + F8_KSC + (t & 3) * STILE + lane * 4);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            i32x8 kf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[s] = *(const i32x8_a16*)(kbuf + kb * (32 * KPITCH) + koff + 64 * s);
+            if (kb == 0) {
+                F8_MFMA_ZERO(S[0], kf[0], qf[0], ksc, qsc, F8_OPS_00);
+                F8_MFMA(S[0], kf[1], qf[1], ksc, qsc, F8_OPS_12);
+            } else {
+                F8_MFMA_ZERO(S[1], kf[0], qf[0], ksc, qsc, F8_OPS_20);
+                F8_MFMA(S[1], kf[1], qf[1], ksc, qsc, F8_OPS_32);
+            }
+        }
+    };
+    auto mask_tail = [&](f32x16 (&S)[2], int t) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (key >= k_len) S[kb][e] = -1e30f;
+            }
+    };
+    auto row_max = [&](const f32x16 (&S)[2]) -> float {
+        float mx = S[0][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[0][e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[1][e]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+
+    // ---- prologue: S(0) and its row maximum ----
+    f32x16 Sa[2], Sb[2];
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                 // every wave's pieces of K(0), K(1), V(0) and their scales landed before its vmcnt(0) above
+    __builtin_amdgcn_sched_barrier(0);
+    qk(0, Sa);
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(Sa[0]), "+v"(Sa[1]));
+    if (nt == 1 && tail_partial) mask_tail(Sa, 0);
+    m_tile = row_max(Sa);
+    m_new = m_tile;
+
+    // ONE body instance per S-buffer role, run-time flags for "a next tile exists" and "it is the masked last one" (wave-uniform
+    // branches).  The bf16 kernel's specialised tail instances are not an option here: hipcc spills accumulators around them, and a
+    // spill store that follows an inline-asm MFMA reads its result before the matrix pipe has written it (the compiler does not know
+    // the statement is an MFMA) -- found as wrong outputs for short key sequences; tests/test_build_resources.py requires 0 scratch.
+    auto body = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
+        const bool MORE = t + 1 < nt;
+        const bool MASK = MORE && tail_partial && (t + 2 == nt);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // all but the two youngest pieces: K(t+1), V(t), their scales are in LDS
+        __builtin_amdgcn_s_barrier();                             // ... for every wave; and every wave is past QK(t), PV(t-1)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t);
+        // deferred rescale (as attn_fwd_pipe_kernel): the row's reference follows its running maximum only after 2^DEFER_T
+        {
+            const bool moved = (m_new - m_run) * K1 > DEFER_T;
+            if (__any(moved)) {
+                F8_MFMA_SETTLE4(O[0], O[1], O[2], O[3]);          // the PV MFMAs of the previous tile may still be in the pipe
+                const float m_ref = moved ? m_new : m_run;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_ref) * K1);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+                m_run = m_ref;
+            }
+        }
+        // block scale of P(t): 2^(et - 8), et = ceil(log2 of the tile's largest weight against the reference) (<= DEFER_T)
+        const float et = fmaxf(__builtin_ceilf((m_tile - m_run) * K1), -100.f);
+        const int pscale = 119 + (int)et;
+        // ---- phase 1: MFMA S(t+1)  ||  VALU: the e4m3 bytes of P(t) ----
+        if (MORE) qk(t + 1, Sn);
+        i32x8 pf;
+        if (PMODE == 1) {
+            // byte = round(8 (log2 units of s - reference - et + 8) + 56) = round(65535 (s - m_run) + 120 - 8 et): v_cvt_pknorm_u16_f32
+            // computes round(65535 clamp(x, 0, 1)); the result is < 256, the low bytes of the two halves are gathered by v_perm_b32
+            const float kc = (120.f - 8.f * et) * (1.0f / 65535.0f) - m_run;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u16x2 u01 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i] + kc, Sc[kb][4 * i + 1] + kc);
+                    const u16x2 u23 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i + 2] + kc, Sc[kb][4 * i + 3] + kc);
+                    pf[kb * 4 + i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, u23), __builtin_bit_cast(unsigned, u01), 0x06040200u);
+                }
+        } else {
+            const float ka = 8.f - et - m_run * K1;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pe[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pe[j] = __builtin_amdgcn_exp2f(Sc[kb][4 * i + j] * K1 + ka);
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(pe[0], pe[1], 0, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(pe[2], pe[3], w, true);
+                    pf[kb * 4 + i] = w;
+                }
+        }
+        // ---- phase 2: MFMA O += V(t)^T P(t)^T, l += 1 P(t)^T  ||  VALU: row maximum of S(t+1) ----
+        {
+            const char* vbuf = smem + F8_VST + (t & 3) * VTILE;
+            const int vsc = *(const int*)(smem + F8_VSC + (t & 3) * STILE + lane * 4);
+            i32x8 vf[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) vf[db] = *(const i32x8_a16*)(vbuf + db * (32 * VPITCH) + voff);
+            // the tile's row sum FIRST, into the registers of S(t) (dead: P(t) has been packed): 1^T P^T has 32 equal rows, element 0 is
+            // added to the running sum once the four MFMAs behind it have been issued (in-order matrix pipe: it has completed by then)
+            F8_MFMA_ZERO_NOP(Sc[0], ones, pf, unit, pscale, F8_OPS_00);
+            F8_MFMA(O[0], vf[0], pf, vsc, pscale, F8_OPS_00);
+            F8_MFMA(O[1], vf[1], pf, vsc, pscale, F8_OPS_10);
+            F8_MFMA(O[2], vf[2], pf, vsc, pscale, F8_OPS_20);
+            F8_MFMA(O[3], vf[3], pf, vsc, pscale, F8_OPS_30);
+        }
+        // S(t+1) and the tile sum were written by MFMAs issued BEFORE the last four (the matrix pipe is in order): readable from here on
+        asm volatile("" : "+v"(Sc[0]));
+        l_run += Sc[0][0];
+        if (MORE) asm volatile("" : "+v"(Sn[0]), "+v"(Sn[1]));
+        if (MORE) {
+            if (MASK) mask_tail(Sn, t + 1);
+            m_tile = row_max(Sn);
+            m_new = fmaxf(m_new, m_tile);
+        }
+    };
+    for (int t = 0; t < nt; t += 2) {
+        body(t, Sa, Sb);
+        if (t + 1 < nt) body(t + 1, Sb, Sa);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may still be landing in LDS when the workgroup retires
+    F8_MFMA_SETTLE4(O[0], O[1], O[2], O[3]);
+
+    const float inv = 1.0f / l_run;
+    const bool wide = (((p.o_ts | p.o_hs | p.o_bs) & 7) == 0) && (((uintptr_t)p.out & 15) == 0);
+    if (wide) {
+        bf16_t* orow = op + (int64_t)q_row_c * p.o_ts + 8 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float va[4], vb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = O[db][8 * j + e] * inv; vb[e] = O[db][8 * j + 4 + e] * inv; }
+                const uint2 pa = pack4(va), pb = pack4(vb);
+                const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+                if (q_row < p.Lq) *(uint4*)(orow + db * 32 + 16 * j) = uint4{sx[0], sy[0], sx[1], sy[1]};
+            }
+    } else if (q_row < p.Lq) {
+        bf16_t* orow = op + (int64_t)q_row * p.o_ts + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v[4] = {O[db][4 * g4] * inv, O[db][4 * g4 + 1] * inv, O[db][4 * g4 + 2] * inv, O[db][4 * g4 + 3] * inv};
+                *(uint2*)(orow + db * 32 + 8 * g4) = pack4(v);
+            }
+    }
+}
+
+inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+int64_t vc_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    const int64_t nTq = (Lq + KT - 1) / KT, nTk = (Lk + KT - 1) / KT, bh = (int64_t)B * H;
+    return up256(bh * nTq * KT * 128) + up256(bh * nTq * KT * 4) + up256(bh * nTk * KTILE) + up256(bh * nTk * VTILE) + 2 * up256(bh * nTk * STILE);
+}
+
+static int fp8_attn_fill(VcAttnFp8Params& p, int64_t ws_bytes) {
+    if (!p.q || !p.k || !p.v || !p.out || !p.ws || p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return VC_E_INVALID;
+    if ((p.q_ts | p.k_ts | p.q_hs | p.k_hs | p.q_bs | p.k_bs) % 8) return VC_E_UNSUPPORTED;      // 16-byte row loads of q and k
+    if ((p.o_ts | p.o_hs | p.o_bs) % 4 || ((uintptr_t)p.ws & 255)) return VC_E_UNSUPPORTED;
+    if (p.pmode != 0 && p.pmode != 1) return VC_E_INVALID;
+    if (ws_bytes < vc_attention_fp8_workspace_bytes(p.B, p.H, p.Lq, p.Lk)) return VC_E_NOMEM;
+    const int64_t nTq = (p.Lq + KT - 1) / KT, nTk = (p.Lk + KT - 1) / KT, bh = (int64_t)p.B * p.H;
+    int64_t off = 0;
+    p.off_q8 = off; off += up256(bh * nTq * KT * 128);
+    p.off_qs = off; off += up256(bh * nTq * KT * 4);
+    p.off_k8 = off; off += up256(bh * nTk * KTILE);
+    p.off_ks = off; off += up256(bh * nTk * STILE);
+    p.off_v8 = off; off += up256(bh * nTk * VTILE);
+    p.off_vs = off;
+    p.qfold = (float)((double)p.scale * 1.4426950408889634 * 8.0 / 65535.0);
+    return VC_OK;
+}
+
+int vc_launch_attention_fp8_quant(VcAttnFp8Params p, int64_t ws_bytes, hipStream_t stream) {
+    const int rc = fp8_attn_fill(p, ws_bytes);
+    if (rc != VC_OK) return rc;
+    const int nTq = (p.Lq + KT - 1) / KT, nTk = (p.Lk + KT - 1) / KT, ntile = nTq > nTk ? nTq : nTk;
+    hipLaunchKernelGGL(attn_quant_fp8_kernel, dim3((unsigned)((int64_t)p.B * p.H * ntile)), dim3(256), 0, stream, p, nTq, nTk, ntile);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+int vc_launch_attention_fp8_core(VcAttnFp8Params p, int64_t ws_bytes, hipStream_t stream) {
+    const int rc = fp8_attn_fill(p, ws_bytes);
+    if (rc != VC_OK) return rc;
+    const int nTq = (p.Lq + KT - 1) / KT, nTk = (p.Lk + KT - 1) / KT;
+    const int nQ = (p.Lq + 255) / 256;
+    const int nwork = p.B * p.H * nQ;
+    const int grid = (nwork + 7) / 8 * 8;
+    static std::atomic<uint64_t> done0{0}, done1{0};
+    if (p.pmode == 1) {
+        if (!vc_set_lds_once(done1, (const void*)attn_fp8_kernel<1>, F8_LDS)) return VC_E_HIP;
+        hipLaunchKernelGGL(attn_fp8_kernel<1>, dim3(grid), dim3(512), F8_LDS, stream, p, nQ, nwork, nTq, nTk);
+    } else {
+        if (!vc_set_lds_once(done0, (const void*)attn_fp8_kernel<0>, F8_LDS)) return VC_E_HIP;
+        hipLaunchKernelGGL(attn_fp8_kernel<0>, dim3(grid), dim3(512), F8_LDS, stream, p, nQ, nwork, nTq, nTk);
+    }
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
+}
+
+int vc_launch_attention_fp8(const VcAttnFp8Params& p, int64_t ws_bytes, hipStream_t stream) {
+    const int rc = vc_launch_attention_fp8_quant(p, ws_bytes, stream);
+    if (rc != VC_OK) return rc;
+    return vc_launch_attention_fp8_core(p, ws_bytes, stream);
+}

@@ -84,6 +84,7 @@ struct Lane {
     void *tb = nullptr, *qkv = nullptr, *attn = nullptr, *hb = nullptr, *mod = nullptr, *send = nullptr, *recv = nullptr;
     // Ulysses x ring hybrid (ring > 1): second K|V block buffer, the R partial outputs and their log-sum-exps; ring events
     void *kv2 = nullptr, *opart = nullptr, *lsep = nullptr;
+    void* f8ws = nullptr; int64_t f8ws_bytes = 0;          // fp8 self-attention: e4m3 copies of q, k, v^T + block scales (vc_set_fp8_attention)
     hipEvent_t rev[3] = {nullptr, nullptr, nullptr};       // 0, 1: attention has finished reading K|V buffer 0 / 1; 2: ring pass landed
 };
 
@@ -130,6 +131,9 @@ struct vc_engine {
         // `fresh_for` (the bf16 buffer the LayerNorm did NOT write) takes the operand as it is
         const void* fresh_for = nullptr; int fresh_M = 0, fresh_K = 0;
     };
+    int fp8_attn = 0;               // fp8 self-attention (vc_set_fp8_attention): 0 off, 1 on;  fp8_attn_pmode: how the weights' bytes are made
+    int fp8_attn_pmode = 1;
+    int64_t f8_one = 0;             // workspace bytes of ONE sample's fp8 attention (sample lanes slice the lane's workspace by it)
     bool fp8_fuse_ln = true;        // VC_FP8_FUSE_LN=0 at vc_create: LayerNorm writes bf16 and the GEMM quantises (tests: bit-equal)
     bool fp8 = false;               // the copies exist
     bool fp8_want = false;          // the mode is on (copies are rebuilt by vc_prepare_video after a weight was re-loaded)
@@ -182,6 +186,7 @@ struct vc_engine {
     struct GraphEntry { uint32_t flags; float scale; int rkey; int seen; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     int graph_mode = -1;            // -1 auto, 0 off, 1 on
+    int64_t graph_replays = 0;      // forwards served by hipGraphLaunch since vc_create (vc_graph_replays: tests assert a replay happened)
     hipStream_t s_cap = nullptr;
     void *gx = nullptr, *gt = nullptr, *gy = nullptr;      // staging: x in, t in, out
 
@@ -249,11 +254,20 @@ int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
         q.Wg[k - 1] = wk->second.q;
         q.w_scaleg[k - 1] = wk->second.scale;
     }
+    q.fp8 = 1; q.ldw = g.K; q.lda = g.K; q.a_rows_padded = 1;
+    // a shape the fp8 kernel does not take (e.g. rows_per_batch < 256 on the gated epilogues of small models): decided BEFORE any
+    // quantiser runs, so such a layer stays bf16 end to end instead of paying a quantiser pass for nothing (round-3 advisor finding)
+    const bool eligible = vc_gemm_fp8_eligible(q);
+    {
+        auto it = h->fp8a.find(s);
+        if (!eligible && !(it != h->fp8a.end() && it->second.fresh_for == g.A)) return VC_OK;
+    }
     int rc = fp8_scratch(h, s, g.M, g.K);
     if (rc != VC_OK) return rc;
     auto& sc = h->fp8a[s];
     const bool fresh = sc.fresh_for == g.A && sc.fresh_M == g.M && sc.fresh_K == g.K;
     sc.fresh_for = nullptr;
+    if (!eligible) return fail(h, VC_E_UNSUPPORTED, "fp8 GEMM %d x %d x %d: the LayerNorm in front of it already wrote an e4m3 operand, but the kernel refuses the shape", g.M, g.N, g.K);
     if (!fresh) {
         rc = vc_launch_quantize_rows_fp8(g.A, g.lda, sc.q, g.K, sc.scale, g.M, g.K, s);
         if (rc != VC_OK) return rc;
@@ -267,29 +281,39 @@ int fp8_gemm(vc_engine* h, const VcGemmParams& g, hipStream_t s, bool* done) {
     return rc;
 }
 
-// the stream's quantised-A scratch, at least rows x cols
+// the stream's quantised-A scratch, at least rows x cols.  Engine-owned streams (adapter lane, graph-capture stream) get theirs in
+// vc_prepare_video, before any capture can be open; a caller's stream gets its scratch at its first eager forward.  While a capture is
+// open on `s` nothing is allocated (hipMalloc / a synchronise are refused there: the capture would be dropped silently and a memset
+// would become a graph node): the call fails instead (round-3 advisor finding).
+bool engine_owns(const vc_engine* h, hipStream_t s) { return s == h->s_adp || s == h->s_cap || s == h->s_comm[0] || s == h->s_comm[1]; }
 int fp8_scratch(vc_engine* h, hipStream_t s, int M, int K) {
     const int64_t rows = ((int64_t)M + 255) / 256 * 256;
-    if (!h->fp8a.count(s) && h->fp8a.size() >= 8) {
-        // a caller that keeps changing streams: the engine itself uses at most five (caller, adapter, two exchange lanes, capture)
-        for (auto& kv : h->fp8a) {
-            (void)hipStreamSynchronize(kv.first);
-            if (kv.second.q) (void)hipFree(kv.second.q);
-            if (kv.second.scale) (void)hipFree(kv.second.scale);
+    const auto have = h->fp8a.find(s);
+    if (have != h->fp8a.end() && have->second.rows >= rows && have->second.cols >= K) return VC_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(h, VC_E_STATE, "fp8 scratch of %lld x %d bytes would have to be allocated inside a stream capture", (long long)rows, K);
+    if (have == h->fp8a.end() && h->fp8a.size() >= 8) {
+        // a caller that keeps changing streams (the engine itself uses three: caller, adapter lane, capture).  The remembered handles
+        // may belong to streams the caller has destroyed since: one device-wide synchronise instead of one per handle, and only the
+        // scratches of foreign streams go
+        (void)hipDeviceSynchronize();
+        for (auto it = h->fp8a.begin(); it != h->fp8a.end();) {
+            if (engine_owns(h, it->first)) { ++it; continue; }
+            if (it->second.q) (void)hipFree(it->second.q);
+            if (it->second.scale) (void)hipFree(it->second.scale);
+            it = h->fp8a.erase(it);
         }
-        h->fp8a.clear();
     }
     auto& sc = h->fp8a[s];
-    if (sc.rows < rows || sc.cols < K) {
-        // sized once per stream for the largest operand of the prepared video (all samples' rows x ffn_dim), so that no later call --
-        // a different batch under cfg_skip, a forward that is being captured into a graph -- ever allocates
-        const int64_t nr = std::max({sc.rows, rows, ((int64_t)h->M + 255) / 256 * 256});
-        const int64_t ncol = std::max({sc.cols, (int64_t)K, (int64_t)h->cfg.ffn_dim});
-        if (sc.q) { (void)hipStreamSynchronize(s); (void)hipFree(sc.q); (void)hipFree(sc.scale); sc = {}; }
-        if (hipMalloc(&sc.q, nr * ncol) != hipSuccess || hipMalloc((void**)&sc.scale, nr * sizeof(float)) != hipSuccess) return VC_E_NOMEM;
-        (void)hipMemsetAsync(sc.q, 0, nr * ncol, s);       // the tile rows past M are read by the kernel (never stored)
-        sc.rows = nr; sc.cols = ncol;
-    }
+    // sized once per stream for the largest operand of the prepared video (all samples' rows x ffn_dim), so that no later call --
+    // a different batch under cfg_skip -- allocates again
+    const int64_t nr = std::max({sc.rows, rows, ((int64_t)h->M + 255) / 256 * 256});
+    const int64_t ncol = std::max({sc.cols, (int64_t)K, (int64_t)h->cfg.ffn_dim});
+    if (sc.q) { (void)hipStreamSynchronize(s); (void)hipFree(sc.q); (void)hipFree(sc.scale); sc = {}; }
+    if (hipMalloc(&sc.q, nr * ncol) != hipSuccess || hipMalloc((void**)&sc.scale, nr * sizeof(float)) != hipSuccess) return VC_E_NOMEM;
+    (void)hipMemsetAsync(sc.q, 0, nr * ncol, s);       // the tile rows past M are read by the kernel (never stored)
+    sc.rows = nr; sc.cols = ncol;
     return VC_OK;
 }
 
@@ -324,6 +348,21 @@ int p_attn(vc_engine* h, const VcAttnParams& a, hipStream_t s, int cls) {
     ProfScope ps(h, s, cls, 4.0 * a.B * a.H * (double)a.Lq * kl * 128.0,
                  2.0 * a.B * a.H * 128.0 * (2.0 * a.Lq + 2.0 * kl));
     return vc_launch_attention(a, s);
+}
+
+// self-attention of a lane in fp8 (the lane's workspace holds the quantised operands); same profile class and algorithmic FLOPs
+int p_attn_self(vc_engine* h, const VcAttnParams& a, Lane& ln, hipStream_t s) {
+    if (!h->fp8_attn || a.lse || a.seg_len || a.pad_merge || !ln.f8ws) return p_attn(h, a, s, VC_PROF_ATTN_SELF);
+    const double kl = (a.k_len > 0 && a.k_len < a.Lk) ? a.k_len : a.Lk;
+    ProfScope ps(h, s, VC_PROF_ATTN_SELF, 4.0 * a.B * a.H * (double)a.Lq * kl * 128.0, 2.0 * a.B * a.H * 128.0 * (2.0 * a.Lq + 2.0 * kl));
+    VcAttnFp8Params f;
+    memset(&f, 0, sizeof f);
+    f.q = a.q; f.q_bs = a.q_bs; f.q_ts = a.q_ts; f.q_hs = a.q_hs;
+    f.k = a.k; f.k_bs = a.k_bs; f.k_ts = a.k_ts; f.k_hs = a.k_hs;
+    f.v = a.v; f.v_bs = a.v_bs; f.v_ts = a.v_ts; f.v_hs = a.v_hs;
+    f.out = a.out; f.o_bs = a.o_bs; f.o_ts = a.o_ts; f.o_hs = a.o_hs;
+    f.B = a.B; f.H = a.H; f.Lq = a.Lq; f.Lk = a.Lk; f.k_len = a.k_len; f.scale = a.scale; f.pmode = h->fp8_attn_pmode; f.ws = ln.f8ws;
+    return vc_launch_attention_fp8(f, ln.f8ws_bytes, s);
 }
 
 void add_slot(vc_engine* h, const std::string& k, std::vector<int64_t> shape) {
@@ -541,7 +580,7 @@ int sa_mid(vc_engine* h, Lane& ln, int B) {
         a.q_hs = a.k_hs = a.v_hs = 128;
         a.out = ln.attn; a.o_bs = (int64_t)Lloc * d; a.o_ts = d; a.o_hs = 128;
         a.H = N; a.Lq = Lloc; a.Lk = Lloc; a.k_len = h->L;
-        VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
+        VCCHK(h, p_attn_self(h, a, ln, s));
         return VC_OK;
     }
     if (h->ring > 1) {
@@ -606,7 +645,7 @@ int sa_mid(vc_engine* h, Lane& ln, int B) {
     // out (send buffer of the return exchange): [B][P_dst = token owner][Lloc][Nl][128] = [B][Lpad][Nl][128]
     a.out = ln.send; a.o_bs = slab; a.o_ts = hd; a.o_hs = 128;
     a.H = Nl; a.Lq = h->Lpad; a.Lk = h->Lpad; a.k_len = h->L;
-    VCCHK(h, p_attn(h, a, s, VC_PROF_ATTN_SELF));
+    VCCHK(h, p_attn_self(h, a, ln, s));
     { int r2 = to_comm(h, ln, 2); if (r2 != VC_OK) return r2; }
     return sp_all_to_all(h, ln, ln.send, ln.recv, sub * 2, "o", B);        // one all-to-all per sample
 }
@@ -901,6 +940,18 @@ int vc_set_fp8_linear(vc_engine* h, int on) {
 
 int vc_fp8_linear(const vc_engine* h) { return h && h->fp8_want ? 1 : 0; }
 
+// fp8 self-attention of the main and adapter blocks (this build; attention_fp8.hip).  Takes effect at the next vc_prepare_video (the
+// quantised operands live in the per-video arena).  Cross-attention (512 keys, bound by reading Q and writing O) and the ring hybrid's
+// per-block attention (needs the log-sum-exp output) stay bf16.
+int vc_set_fp8_attention(vc_engine* h, int on, int pmode) {
+    if (!h) return VC_E_INVALID;
+    if (pmode != 0 && pmode != 1) return fail(h, VC_E_INVALID, "vc_set_fp8_attention: pmode must be 0 (v_exp_f32) or 1 (piecewise-linear 2^x)");
+    if ((h->fp8_attn != 0) != (on != 0) || h->fp8_attn_pmode != pmode) { drop_graphs(h); h->prepared = false; }
+    h->fp8_attn = on != 0; h->fp8_attn_pmode = pmode;
+    return VC_OK;
+}
+int vc_fp8_attention(const vc_engine* h) { return h ? h->fp8_attn : 0; }
+
 int vc_load_weight(vc_engine* h, const char* key, const void* dev_ptr, int dtype, int ndim, const int64_t* shape) {
     if (!h || !key || !dev_ptr || !shape) return fail(h, VC_E_INVALID, "vc_load_weight: null argument");
     if (dtype != 0) return fail(h, VC_E_UNSUPPORTED, "vc_load_weight(%s): only bf16 (dtype 0) weights", key);
@@ -1088,7 +1139,12 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     }
     const int nlanes = h->dual ? 2 : 1;
     const int64_t o_x = take(md), o_c = take(md), o_c0 = take(md);
-    int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2], o_kv2[2], o_opart[2], o_lsep[2];
+    int64_t o_hint[2], o_tb[2], o_qkv[2], o_attn[2], o_hb[2], o_mod[2], o_send[2], o_recv[2], o_kv2[2], o_opart[2], o_lsep[2], o_f8[2];
+    // fp8 self-attention workspace of a lane: the attention sees (B samples, N / U heads, the group's U * Lloc tokens); a sample lane
+    // works on one sample and takes its slice
+    const int f8_heads = c.num_heads / (P / h->ring), f8_L = Lloc * (P / h->ring);
+    const int64_t f8_one = h->fp8_attn ? vc_attention_fp8_workspace_bytes(1, f8_heads, f8_L, f8_L) : 0;
+    const int64_t f8_all = h->fp8_attn ? std::max(vc_attention_fp8_workspace_bytes(B, f8_heads, f8_L, f8_L), B * f8_one) : 0;
     const bool ringed = h->sp_exchange && h->ring > 1;
     const int64_t lse_b = (int64_t)c.num_heads * Lloc * 4;        // log-sum-exps of one sample and one ring step: [N / U][U * Lloc] floats
     for (int l = 0; l < 2; ++l) {
@@ -1098,10 +1154,11 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
             o_send[l] = take(h->sp_exchange ? 3 * md : 256); o_recv[l] = take(h->sp_exchange ? 3 * md : 256);
             o_kv2[l] = take(ringed ? 2 * md : 256); o_opart[l] = take(ringed ? h->ring * md : 256);
             o_lsep[l] = take(ringed ? h->ring * B * lse_b : 256);
+            o_f8[l] = take(f8_all > 0 ? f8_all : 256);
         } else {
             o_hint[l] = o_hint[0]; o_tb[l] = o_tb[0]; o_qkv[l] = o_qkv[0]; o_attn[l] = o_attn[0]; o_hb[l] = o_hb[0];
             o_mod[l] = o_mod[0]; o_send[l] = o_send[0]; o_recv[l] = o_recv[0];
-            o_kv2[l] = o_kv2[0]; o_opart[l] = o_opart[0]; o_lsep[l] = o_lsep[0];
+            o_kv2[l] = o_kv2[0]; o_opart[l] = o_opart[0]; o_lsep[l] = o_lsep[0]; o_f8[l] = o_f8[0];
         }
     }
     const int kmax = (c.geoada_in_dim > c.in_dim ? c.geoada_in_dim : c.in_dim) * 4;
@@ -1141,8 +1198,10 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
         ln.tb = a + o_tb[l]; ln.qkv = a + o_qkv[l]; ln.attn = a + o_attn[l]; ln.hb = a + o_hb[l]; ln.mod = a + o_mod[l];
         ln.send = a + o_send[l]; ln.recv = a + o_recv[l];
         ln.kv2 = a + o_kv2[l]; ln.opart = a + o_opart[l]; ln.lsep = a + o_lsep[l];
+        ln.f8ws = f8_all > 0 ? a + o_f8[l] : nullptr; ln.f8ws_bytes = f8_all;
         for (int k = 0; k < 3; ++k) ln.rev[k] = h->ev_ring[l][k];
     }
+    h->f8_one = f8_one;
     h->f_sin = (float*)(a + o_fsin); h->f_h = (float*)(a + o_fh); h->f_e = (float*)(a + o_fe);
     h->f_e0 = (float*)(a + o_fe0);
     for (int i = 0; i < nblk; ++i) {
@@ -1155,6 +1214,12 @@ int vc_prepare_video(vc_engine* h, const void* geoada_context, const void* const
     h->M = M; h->tok_off = h->rank * Lloc;
     for (int k = 0; k < 2; ++k)
         if (h->resid_L[k] != Lloc) h->resid_B[k] = 0;        // another token geometry: the stored residual is meaningless
+    if (h->fp8) {
+        // quantised-operand scratch of the engine's own GEMM streams, before any capture can be open on them
+        const bool graphs = h->lane_mode == 0 && !h->sp_exchange && (h->graph_mode < 0 ? M <= 16384 : h->graph_mode == 1);
+        if (graphs) { int r = fp8_scratch(h, h->s_cap, M, f); if (r != VC_OK) return r == VC_E_NOMEM ? fail(h, r, "fp8 scratch: out of device memory") : r; }
+        if (h->lane_mode == 1 || h->lane_mode == 2) { int r = fp8_scratch(h, h->s_adp, M, f); if (r != VC_OK) return r == VC_E_NOMEM ? fail(h, r, "fp8 scratch: out of device memory") : r; }
+    }
 
     // ---- control-map patch embedding (VC.py:262-270): c0 = Conv3d(geoada_context), zero-padded rows ----
     VCCHK(h, vc_launch_patchify(geoada_context, h->patchA, B, c.geoada_in_dim, T, H, Wd, Lloc, h->tok_off, s));
@@ -1272,6 +1337,7 @@ static int forward_impl(vc_engine* h, const void* x, const float* t, void* out, 
                 // ring buffers of one sample: [2][1][..] K|V, [R][1][..] partial outputs, [R][1][..] log-sum-exps
                 v.kv2 = (char*)L0.kv2 + rows * 2 * d * 2; v.opart = (char*)L0.opart + rows * h->ring * d * 2;
                 v.lsep = (char*)L0.lsep + (int64_t)b * h->ring * c.num_heads * Lloc * 4;
+                v.f8ws = L0.f8ws ? (char*)L0.f8ws + (int64_t)b * h->f8_one : nullptr; v.f8ws_bytes = h->f8_one;
                 for (int k = 0; k < 3; ++k) v.rev[k] = h->ev_ring[b][k];
             }
             if (h->lane_mode == 2) {
@@ -1458,6 +1524,7 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
         HIPCHK(h, hipMemcpyAsync(h->gx, x, (size_t)nx, hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipMemcpyAsync(h->gt, t, (size_t)h->B * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipGraphLaunch(ge->exec, s));
+        ++h->graph_replays;
         HIPCHK(h, hipMemcpyAsync(out, h->gy, (size_t)ny, hipMemcpyDeviceToDevice, s));
     } else {
         rc = forward_impl(h, x, t, out, geoada_context_scale, flags, s);
@@ -1466,6 +1533,14 @@ int vc_forward(vc_engine* h, const void* x, const float* t, void* out, float geo
     if (rc == VC_OK && run_main && store_res) { h->resid_B[slot] = h->B; h->resid_L[slot] = h->Lloc; }
     return rc;
 }
+
+int vc_reset_residuals(vc_engine* h) {
+    if (!h) return VC_E_INVALID;
+    h->resid_B[0] = h->resid_B[1] = 0;          // the slots stay allocated; a USE_RESIDUAL before the next STORE fails with VC_E_STATE
+    return VC_OK;
+}
+
+int64_t vc_graph_replays(const vc_engine* h) { return h ? h->graph_replays : 0; }
 
 int vc_profile_enable(vc_engine* h, int on) {
     if (!h) return VC_E_INVALID;
@@ -1514,6 +1589,26 @@ int vc_op_attention(const void* q, const void* k, const void* v, void* out, int 
     a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale;
     return vc_launch_attention(a, (hipStream_t)stream);
+}
+
+// fp8 self-attention in isolation (attention_fp8.hip): stage 0 = quantise + attend, 1 = quantise only, 2 = attend only (a workspace a
+// stage-1 call filled for the same shape)
+int64_t vc_op_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk) { return vc_attention_fp8_workspace_bytes(B, H, Lq, Lk); }
+int vc_op_attention_fp8(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk, const int64_t* qs,
+                        const int64_t* ks, const int64_t* vs, const int64_t* os, int k_len, float scale, int pmode, int stage, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+    if (!qs || !ks || !vs || !os) return VC_E_INVALID;
+    VcAttnFp8Params a;
+    memset(&a, 0, sizeof a);
+    a.q = q; a.q_bs = qs[0]; a.q_ts = qs[1]; a.q_hs = qs[2];
+    a.k = k; a.k_bs = ks[0]; a.k_ts = ks[1]; a.k_hs = ks[2];
+    a.v = v; a.v_bs = vs[0]; a.v_ts = vs[1]; a.v_hs = vs[2];
+    a.out = out; a.o_bs = os[0]; a.o_ts = os[1]; a.o_hs = os[2];
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.k_len = k_len; a.scale = scale; a.pmode = pmode; a.ws = workspace;
+    if (stage == 1) return vc_launch_attention_fp8_quant(a, workspace_bytes, (hipStream_t)stream);
+    if (stage == 2) return vc_launch_attention_fp8_core(a, workspace_bytes, (hipStream_t)stream);
+    if (stage != 0) return VC_E_INVALID;
+    return vc_launch_attention_fp8(a, workspace_bytes, (hipStream_t)stream);
 }
 
 int vc_op_attention_variant(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,

@@ -998,22 +998,28 @@ int launch_cfg(const VcGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// shapes / alignments the fp8 instantiation of the ping-pong kernel takes (operand POINTERS other than A, W, C are not looked at: the
+// engine asks before it has quantised anything)
+bool vc_gemm_fp8_eligible(const VcGemmParams& p) {
+    const bool rows_ok8 = (p.M % 256 == 0) || p.a_rows_padded;
+    bool ok = rows_ok8 && p.M > 0 && p.N % 256 == 0 && p.K % 256 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.ldc % 8 == 0 &&
+              ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 &&
+              (p.rows_per_batch == 0 || p.rows_per_batch >= 256) && p.lda * 256 < (1ll << 31) && p.ldw * 256 < (1ll << 31);
+    if (p.resid) ok = ok && p.ldr % 8 == 0 && ((uintptr_t)p.resid & 15) == 0;
+    if (p.hint) ok = ok && p.ldh % 8 == 0 && ((uintptr_t)p.hint & 15) == 0;
+    for (int g = 1; g < p.ngroups; ++g) ok = ok && ((uintptr_t)p.Cg[g - 1] & 15) == 0;
+    return ok && (p.epilogue == VC_EPI_BIAS || p.epilogue == VC_EPI_BIAS_GELU || p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID);
+}
+
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return VC_E_INVALID;
     if (p.fp8) {      // e4m3 operands: the ping-pong kernel or nothing
         if (!p.a_scale || !p.w_scale) return VC_E_INVALID;
         for (int g = 1; g < p.ngroups; ++g)
             if (!p.Wg[g - 1] || !p.Cg[g - 1] || !p.w_scaleg[g - 1]) return VC_E_INVALID;
-        const bool rows_ok8 = (p.M % 256 == 0) || p.a_rows_padded;
-        bool ok = rows_ok8 && p.N % 256 == 0 && p.K % 256 == 0 && p.lda % 16 == 0 && p.ldw % 16 == 0 && p.ldc % 8 == 0 &&
-                  ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0 &&
-                  (p.rows_per_batch == 0 || p.rows_per_batch >= 256) && p.lda * 256 < (1ll << 31) && p.ldw * 256 < (1ll << 31) &&
-                  ((uintptr_t)p.w_scale & 15) == 0;
-        if (p.resid) ok = ok && p.ldr % 8 == 0 && ((uintptr_t)p.resid & 15) == 0;
-        if (p.hint) ok = ok && p.ldh % 8 == 0 && ((uintptr_t)p.hint & 15) == 0;
         if ((p.epilogue == VC_EPI_BIAS_RESID || p.epilogue == VC_EPI_BIAS_GATE_RESID) && !p.resid) return VC_E_INVALID;
         if (p.epilogue == VC_EPI_BIAS_GATE_RESID && !p.gate) return VC_E_INVALID;
-        return ok ? launch_pp_fp8(p, stream) : VC_E_UNSUPPORTED;
+        return vc_gemm_fp8_eligible(p) && ((uintptr_t)p.w_scale & 15) == 0 ? launch_pp_fp8(p, stream) : VC_E_UNSUPPORTED;
     }
     if (p.K % 64 != 0 || p.N % 4 != 0) return VC_E_UNSUPPORTED;
     if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 4)) return VC_E_UNSUPPORTED;

@@ -47,6 +47,7 @@ struct VcGemmParams {
     const float* w_scaleg[2];
 };
 int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream);
+bool vc_gemm_fp8_eligible(const VcGemmParams& p);     // with p.fp8 operands in place (A, W e4m3): would vc_launch_gemm take the shape?
 int vc_launch_layernorm_q8(const void* x, void* q, float* qscale, int rows, int dim, int rows_per_batch, float eps, int mode,
                            const void* p0, const void* p1, int64_t p_bstride, hipStream_t stream);
 int vc_launch_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, hipStream_t stream);
@@ -86,6 +87,28 @@ struct VcAttnMergeParams {
 };
 int vc_launch_attention_merge(const VcAttnMergeParams& p, hipStream_t stream);
 int vc_launch_attention_stream(const VcAttnParams& p, hipStream_t stream);     // attention_stream.hip (5-8 key tiles, padded-key folding)
+
+// ---- fp8 self-attention (attention_fp8.hip; opt-in mode of this build, BASELINE config 5's dtype) ----------------------------------
+// q, k, v bf16 with element strides (batch, token, head), D = 128 contiguous; out bf16.  ws: 256-byte aligned device workspace of at least
+// vc_attention_fp8_workspace_bytes(B, H, Lq, Lk) bytes (the e4m3 copies of q, k, v^T and their E8M0 block scales).
+// pmode 1: P's e4m3 byte from the piecewise-linear 2^x (no exponential); pmode 0: v_exp_f32 + v_cvt_pk_fp8_f32.
+struct VcAttnFp8Params {
+    const void* q; int64_t q_bs, q_ts, q_hs;
+    const void* k; int64_t k_bs, k_ts, k_hs;
+    const void* v; int64_t v_bs, v_ts, v_hs;
+    void* out;     int64_t o_bs, o_ts, o_hs;
+    int B, H, Lq, Lk, k_len;
+    float scale;
+    int pmode;
+    void* ws;
+    // filled by the launcher
+    int64_t off_q8, off_qs, off_k8, off_ks, off_v8, off_vs;
+    float qfold;
+};
+int64_t vc_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk);
+int vc_launch_attention_fp8(const VcAttnFp8Params& p, int64_t ws_bytes, hipStream_t stream);          // quantise + attend
+int vc_launch_attention_fp8_quant(VcAttnFp8Params p, int64_t ws_bytes, hipStream_t stream);           // the two halves (tests, profiling)
+int vc_launch_attention_fp8_core(VcAttnFp8Params p, int64_t ws_bytes, hipStream_t stream);
 
 // ---- row kernels --------------------------------------------------------------------------
 // y = LN(x) * (1 + scale[b]) + shift[b]        (mode 0, WT.py:591,603; head WT.py:643)

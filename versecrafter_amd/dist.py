@@ -27,9 +27,10 @@ from . import _lib
 _SP_GROUP = None
 _BP_GROUP = None       # batch-parallel group (the samples of a CFG pair on different ranks); None = off
 _RING_DEGREE = 1       # the ring degree the caller asked for (set_multi_gpus_devices); see choose_ring_degree
+_RING_AS_GIVEN = False # True: a valid requested ring degree is used as it is (the reference's documented layout), never folded into Ulysses
 
 
-def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1):
+def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: int = 1, ring_as_given: bool = False):
     """CLI.py:180.  One process per GPU (torchrun env); returns this rank's device.  The reference's
     ulysses x ring hybrid is run as pure Ulysses of degree ulysses*ring when the model's head count divides by it (14B: 40 heads),
     else as the hybrid with a ring of `ring_degree` (choose_ring_degree; the engine's vc_sp_set_ring).
@@ -38,10 +39,15 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
     classifier-free guidance, PIPE.py:878-887 -- are independent units, so `cfg_degree` ranks can take one sample each with no
     data-path collective at all; only the noise prediction (4 MB at cfg-3) is all-gathered after the forward.  World size =
     cfg_degree * ulysses_degree * ring_degree; rank r works on sample r // S inside the Ulysses group of its S = ulysses * ring
-    neighbours [r - r % S, r - r % S + S)."""
-    global _RING_DEGREE
+    neighbours [r - r % S, r - r % S + S).
+
+    ring_as_given (this build; CLI `--sp_layout as_given`): run exactly `ulysses_degree x ring_degree` -- the reference's documented
+    launch line (`inference.sh:62-71`: 2 x 4 / 4 x 2) -- even where pure Ulysses of the product would fit the head count, so that the two
+    layouts can be compared on hardware with one flag."""
+    global _RING_DEGREE, _RING_AS_GIVEN
     degree = int(ulysses_degree) * int(ring_degree)
     _RING_DEGREE = int(ring_degree)
+    _RING_AS_GIVEN = bool(ring_as_given)
     cfg_degree = int(cfg_degree)
     world = degree * cfg_degree
     if world > 1:
@@ -55,7 +61,7 @@ def set_multi_gpus_devices(ulysses_degree: int, ring_degree: int, cfg_degree: in
                                     ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"))
         if dist.get_world_size() != world:
             raise ValueError(f"cfg_degree*ulysses_degree*ring_degree = {world} but world size is {dist.get_world_size()}")
-        if int(ring_degree) > 1 and dist.get_rank() == 0:
+        if int(ring_degree) > 1 and dist.get_rank() == 0 and not ring_as_given:
             print(f"[versecrafter_amd] ulysses_degree={ulysses_degree} x ring_degree={ring_degree}: run as pure Ulysses of degree {degree} when the "
                   "model's head count divides by it, else as the Ulysses x ring hybrid (dist.choose_ring_degree)")
         make_groups(degree, cfg_degree)
@@ -105,7 +111,11 @@ def get_ring_degree() -> int:
     return _RING_DEGREE
 
 
-def choose_ring_degree(world: int, num_heads: int, requested: int = 1) -> int:
+def ring_as_given() -> bool:
+    return _RING_AS_GIVEN
+
+
+def choose_ring_degree(world: int, num_heads: int, requested: int = 1, as_given: bool = None) -> int:
     """Ring degree R of a sequence-parallel world (Ulysses degree U = world / R must divide num_heads).
     VC_SP_RING forces one (tests).  Otherwise: 1 -- pure Ulysses, two all-to-alls per attention and no partial-output merge -- whenever
     the head count allows it (Wan2.1-14B: 40 heads, any world in {1, 2, 4, 5, 8}; this is how the reference's default 4 x 2 has always
@@ -116,6 +126,12 @@ def choose_ring_degree(world: int, num_heads: int, requested: int = 1) -> int:
         if r < 1 or world % r or num_heads % (world // r):
             raise ValueError(f"VC_SP_RING={r}: world {world} / ring must divide num_heads {num_heads}")
         return r
+    if as_given is None:
+        as_given = _RING_AS_GIVEN
+    if as_given and requested >= 1:         # the caller's U x R exactly (set_multi_gpus_devices(ring_as_given=True))
+        if world % requested or num_heads % (world // requested) or requested > 8:
+            raise ValueError(f"ring degree {requested}: world {world} / ring must divide num_heads {num_heads} (and the ring be <= 8)")
+        return requested
     if num_heads % world == 0:
         return 1
     valid = [r for r in range(2, min(world, 8) + 1) if world % r == 0 and num_heads % (world // r) == 0]

@@ -308,6 +308,16 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
     def disable_teacache(self):
         self.teacache = None
 
+    def reset_residuals(self):
+        """Forget the TeaCache residuals the engine holds (previous_residual_cond / _uncond of the third-party TeaCache class live in
+        HBM here): the sampler calls this at the start of every video, next to TeaCache.reset()."""
+        if self._engine is not None:
+            _lib.check(_lib.load().vc_reset_residuals(self._engine), self._engine)
+
+    def graph_replays(self) -> int:
+        """Forwards served by a hipGraph replay so far (launch-bound sizes only)."""
+        return 0 if self._engine is None else int(_lib.load().vc_graph_replays(self._engine))
+
     def enable_cfg_skip(self, cfg_skip_ratio, num_steps):
         if cfg_skip_ratio != 0:
             self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = cfg_skip_ratio, 0, num_steps
@@ -336,6 +346,16 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
         self._fp8_linear = bool(on)
         if self._engine is not None:
             _lib.check(_lib.load().vc_set_fp8_linear(self._engine, int(self._fp8_linear)), self._engine)
+            self._video_key = self._video_ident = None
+
+    def enable_fp8_attention(self, on: bool = True, pmode: int = 1):
+        """(this build; BASELINE config 5's dtype -- the reference's self-attention is bf16 flash-attn, WT.py:394-399) Run the SELF-attention
+        of the main and adapter blocks in fp8: q, k, v and the softmax weights as OCP e4m3 under one power-of-two scale per 32 elements
+        along each contraction, both products on v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 accumulation (csrc/attention_fp8.hip).
+        pmode 1: the weights' bytes from the piecewise-linear 2^x (no exponential); pmode 0: v_exp_f32.  Cross-attention stays bf16."""
+        self._fp8_attention = (bool(on), int(pmode))
+        if self._engine is not None:
+            _lib.check(_lib.load().vc_set_fp8_attention(self._engine, int(bool(on)), int(pmode)), self._engine)
             self._video_key = self._video_ident = None
 
     def enable_multi_gpus_inference(self, sp_group=None, batch_group=None):
@@ -424,6 +444,8 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
             self._engine = h
             if getattr(self, "_fp8_linear", False):
                 _lib.check(lib.vc_set_fp8_linear(h, 1), h)        # copies are built once the weights are loaded (vc_prepare_video)
+            if getattr(self, "_fp8_attention", (False, 1))[0]:
+                _lib.check(lib.vc_set_fp8_attention(h, 1, self._fp8_attention[1]), h)
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):                                      # .to() / .cuda() / .bfloat16(): parameters move

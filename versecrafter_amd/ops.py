@@ -100,6 +100,28 @@ def attention(q, k, v, k_len=0, scale=None, out=None, variant=0):
     return out
 
 
+def attention_fp8(q, k, v, k_len=0, scale=None, pmode=1, out=None, workspace=None, stage=0, return_workspace=False):
+    """fp8 self-attention (this build; csrc/attention_fp8.hip): bf16 q [B,Lq,H,128], k / v [B,Lk,H,128] -> bf16 [B,Lq,H,128]; q, k, v and the
+    softmax weights are e4m3 under MX-style block scales inside.  pmode 1: piecewise-linear 2^x for the weights' bytes; 0: v_exp_f32."""
+    lib = _lib.load()
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if out is None:
+        out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    need = int(lib.vc_op_attention_fp8_workspace_bytes(B, H, Lq, Lk))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    assert workspace.dtype == torch.uint8 and workspace.numel() >= need and workspace.data_ptr() % 256 == 0
+    st = lambda t: _lib.i64x3(t.stride(0), t.stride(1), t.stride(2))
+    _lib.check(lib.vc_op_attention_fp8(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Lq, Lk, st(q), st(k), st(v), st(out), int(k_len),
+                                       float(scale), int(pmode), int(stage), _ptr(workspace), workspace.numel(), _stream()))
+    return (out, workspace) if return_workspace else out
+
+
 def attention_lse(q, k, v, k_len=0, scale=None):
     """attention() over one block of keys -> (out [B,Lq,H,128] bf16, lse [B,H,Lq] float32: log2 of the row's sum of exp2(logit * scale * log2 e))."""
     lib = _lib.load()

@@ -193,6 +193,18 @@ class WanVerseCrafterPipeline:
         self.check_inputs(prompt, height, width, negative_prompt, prompt_embeds, negative_prompt_embeds)
         self._guidance_scale = guidance_scale
         self._interrupt = False
+        # A new video: every expert's TeaCache starts from step 0 and the engines forget their stored residuals.  With ONE expert the
+        # reference's own reset (cnt == num_steps at the end of forward, VC.py:438-441) already does this; with two experts each gate only
+        # counts the steps its expert ran, never reaches num_steps, and call 2 would otherwise start past num_skip_start_steps with the
+        # previous video's modulated input and residual (round-3 advisor finding).  A TeaCache shared by the pair is reset once.
+        seen = set()
+        for m in (self.transformer, self.transformer_2):
+            tc = getattr(m, "teacache", None)
+            if tc is not None and id(tc) not in seen:
+                seen.add(id(tc))
+                tc.reset()
+            if m is not None and hasattr(m, "reset_residuals"):
+                m.reset_residuals()
         batch_size = 1 if isinstance(prompt, str) else (len(prompt) if prompt is not None else len(prompt_embeds))
         device = self._execution_device
         weight_dtype = next(self.transformer.parameters()).dtype
