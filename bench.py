@@ -46,6 +46,8 @@ WORKLOADS = {
     "wan14b-81f-720x1280": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), 81, 720, 1280),   # BASELINE config 4
     "wan1.3b-9f-320x512": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), 9, 320, 512),
     "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=4, text_dim=64, text_len=48), 9, 64, 96),
+    # four heads: on 4 ranks all THREE layouts of an N >= 4 run exist (Ulysses-4, CFG pair x Ulysses-2, Ulysses 2 x ring 2): launch rehearsals
+    "tiny4h": (dict(dim=512, ffn_dim=1024, num_heads=4, num_layers=4, text_dim=64, text_len=48), 9, 64, 96),
 }
 
 
@@ -155,6 +157,7 @@ def parse_args(argv=None):
     ap.add_argument("--fp8-linear", action="store_true",
                     help="run the blocks' nn.Linear layers in fp8 (BASELINE config 5's dtype; NOT the headline: the reference computes in "
                          "bf16) -- the line then says dtype 'fp8 e4m3 linear layers (fp32 accumulate) + bf16 attention'")
+    ap.add_argument("--single-layout", action="store_true", help="N >= 4: time Ulysses-N only (no alternative layouts in the same run)")
     ap.add_argument("--ring-degree", type=int, default=1,
                     help="ring degree R of the sequence-parallel group (Ulysses x ring hybrid, the reference's --ring_degree): the Ulysses "
                          "degree becomes ranks / R.  Default 1: pure Ulysses -- what the 14B model's 40 heads allow on 1 / 2 / 4 / 8 GPUs")
@@ -361,6 +364,27 @@ def launch_ranks(args):
                     else:
                         line = lines[0]
                 break
+            # the first layout of this attempt was measured and saved before a LATER (alternative) layout took the run down: that line
+            # is the result; what happened afterwards travels with it
+            part_path = os.path.join(status_dir, f"rank0.a{a}.partial")
+            if 0 in mine and os.path.exists(part_path):
+                try:
+                    saved = json.loads(open(part_path).read())
+                    saved["alt_error"] = why
+                    line, rc_final = json.dumps(saved), 0
+                    print(f"bench.py: attempt {a}: {why} -- AFTER the first layout had been measured: reporting that line", file=sys.stderr)
+                except (OSError, ValueError):
+                    pass
+            if under_launcher:
+                if 0 in mine:
+                    board.set(f"partial{a}", "1" if rc_final == 0 else "0")
+                try:
+                    if board.get(f"partial{a}", timeout=30.0) == "1":
+                        rc_final = 0
+                except Exception:      # noqa: BLE001 -- rank 0's supervisor is gone: nothing to report
+                    pass
+            if rc_final == 0:
+                break
             retry = kind in ("stall", "transport") and a + 1 < len(attempts) and time.time() - t_begin < budget
             if not retry:
                 break
@@ -391,6 +415,9 @@ def main():
     if args.gpus > 1 and os.environ.get("VC_BENCH_CHILD") != "1":
         sys.exit(launch_ranks(args))
     run_rank(args)
+
+
+T_RANK_START = time.time()
 
 
 def run_rank(args):
@@ -443,14 +470,24 @@ def run_rank(args):
     # ---- layouts: (cfg_degree, sp_degree).  N = 2 measures BOTH ways of using two GPUs in this one run -- Ulysses over the two
     # ranks (north_star's curve) and one CFG sample per rank (no data-path collective: DESIGN.md 6); the faster one is the
     # headline, the other goes under "alt".  N >= 4: Ulysses over all ranks.  --cfg-degree pins one layout.
+    # A layout is (cfg_degree, sp_degree, ring): ring 0 = the bench's own choice (--ring-degree, else pure Ulysses where the heads allow).
+    # N >= 4 (round 4): north_star's Ulysses-N first -- its line is saved as soon as it is measured --, then, time permitting, two
+    # alternatives of the SAME run: the CFG pair on two Ulysses groups of N/2 (half the all-to-all bytes and peers per exchange) and the
+    # reference's documented launch line, Ulysses 2 x ring N/2 (inference.sh:62-71: 2 x 4 on 8 GPUs).  A second attempt of the supervised
+    # launch (fallback transport) and --single-layout measure the first layout only.
+    attempt = int(os.environ.get("VC_BENCH_ATTEMPT", "0"))
     if args.cfg_degree:
         if world % args.cfg_degree:
             raise SystemExit(f"--cfg-degree {args.cfg_degree} does not divide --gpus {world}")
-        layouts = [(args.cfg_degree, world // args.cfg_degree)]
+        layouts = [(args.cfg_degree, world // args.cfg_degree, 0)]
     elif world == 2:
-        layouts = [(1, 2), (2, 1)]
+        layouts = [(1, 2, 0), (2, 1, 0)]
+    elif world >= 4 and world % 2 == 0 and attempt == 0 and not args.single_layout and args.ring_degree <= 1:
+        layouts = [(1, world, 0), (2, world // 2, 0)]
+        if mk["num_heads"] % 2 == 0 and mk["num_heads"] % world == 0 and world // 2 <= 8:
+            layouts.append((1, world, world // 2))
     else:
-        layouts = [(1, world)]
+        layouts = [(1, world, 0)]
     groups, sps, observed = {}, {}, {}
     vdist = None
     if use_dist:
@@ -463,6 +500,8 @@ def run_rank(args):
         and the smallest ring that fits where it does not (1.3B: 12 heads on 8 ranks -> 4 x 2), as the CLI chooses."""
         if lay[1] <= 1:
             return 1
+        if lay[2] > 0:
+            return lay[2]
         return args.ring_degree if args.ring_degree > 1 else vdist.choose_ring_degree(lay[1], mk["num_heads"], 1)
 
     configured = [None]
@@ -564,15 +603,9 @@ def run_rank(args):
         return {"layout": lay, "elapsed": elapsed, "prof": prof, "finite": finite, "observed": obs,
                 "transport": getattr(model._sp, "transport", "none") if lay[1] > 1 or (world == 1 and use_dist) else "none"}
 
-    results = [timed(lay) for lay in layouts]
-
-    tea = None
-    if world == 1 and not use_dist and not args.no_teacache_line:
-        tea = teacache_line(args, model, pipe, scheduler, latents, embeds, geoada_in, seq_len, ts, dev)
-
-    if rank == 0:
+    def build_out(results, tea, final, skipped=()):
         def line_of(res):
-            cfgd, spd = res["layout"]
+            cfgd, spd = res["layout"][:2]
             sps_ = args.steps / res["elapsed"]
             obs = res["observed"]
             sp_ranks = int(obs.get("sp", {}).get("ranks", 0) or 0)
@@ -678,9 +711,40 @@ def run_rank(args):
             out["breakdown"] = bd
         if tea is not None:
             out["teacache_on"] = tea
-        if world == 1 and not args.no_cpu_baseline:
+        if skipped:
+            out["alt_skipped"] = [f"cfg{c} x ulysses-sp{sp_}" + (f" ring {r_}" if r_ else "") + ": not timed (the run was past its time mark)" for c, sp_, r_ in skipped]
+        if final and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mk, f_step, L)
-        real_stdout.write(json.dumps(out) + "\n")
+        return out
+
+    # Layouts are timed in order.  With alternatives (N >= 4) the first layout's line is SAVED the moment it exists (the supervisor
+    # prints it if a later layout takes the run down), and an alternative is only started while the run is young enough
+    # (VC_BENCH_ALT_DEADLINE seconds since this rank started, default 300; every rank takes rank 0's decision).
+    results, skipped = [], []
+    alt_deadline = float(os.environ.get("VC_BENCH_ALT_DEADLINE", "300"))
+    for i, lay in enumerate(layouts):
+        if i > 0 and world >= 4:
+            go = torch.tensor([1.0 if time.time() - T_RANK_START < alt_deadline else 0.0])
+            if use_dist:
+                dist.broadcast(go, src=0)
+            if go.item() < 0.5:
+                skipped.append(lay)
+                continue
+        results.append(timed(lay))
+        if i == 0 and len(layouts) > 1 and world >= 4 and rank == 0:
+            d = os.environ.get("VC_BENCH_STATUS_DIR")
+            if d:
+                part = build_out(results, None, False)
+                part["alt_note"] = "first layout only: the run ended before its alternative layouts were timed"
+                with open(os.path.join(d, f"rank0.a{os.environ.get('VC_BENCH_ATTEMPT', '0')}.partial"), "w") as fh:
+                    fh.write(json.dumps(part) + "\n")
+
+    tea = None
+    if world == 1 and not use_dist and not args.no_teacache_line:
+        tea = teacache_line(args, model, pipe, scheduler, latents, embeds, geoada_in, seq_len, ts, dev)
+
+    if rank == 0:
+        real_stdout.write(json.dumps(build_out(results, tea, True, skipped)) + "\n")
         real_stdout.flush()
     if use_dist:
         dist.all_reduce(torch.zeros(1))

@@ -268,4 +268,11 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    from versecrafter_amd.dist import SequenceParallelStall
+    try:
+        main()
+    except SequenceParallelStall as stall:
+        # the rendezvous of the engine's communicators never returned on this rank: a helper thread is still inside it.  No interpreter
+        # shutdown (it would destroy the engine under that thread): say why and leave at once, non-zero; torchrun ends the other ranks
+        print(f"versecrafter_inference: {stall}", file=sys.stderr, flush=True)
+        os._exit(3)

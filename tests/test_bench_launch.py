@@ -88,6 +88,17 @@ def test_supervisor_budget_bounds_the_whole_run(tmp_path):
     assert time.time() - t0 < 30
 
 
+@pytest.mark.parametrize("mode,needle", [("hang_in_alt", "over the run budget"), ("die_in_alt", "rank 1 exited with code 5")])
+def test_supervisor_reports_the_first_layout_when_an_alternative_layout_takes_the_run_down(tmp_path, mode, needle):
+    """N >= 4 times Ulysses-N first and saves its line; the alternative layouts of the same run (CFG pair on two Ulysses groups, the
+    reference's Ulysses 2 x ring N/2) come after it.  A hang or a death inside one of them must not cost the measured line."""
+    r = _run(["--gpus", "2"], env=dict(FAST, FAKE_MODE=mode, VC_BENCH_BUDGET="6", VC_BENCH_LOG_DIR=str(tmp_path)), timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip())
+    assert out["value"] == 2.5 and out["alt_note"] == "first layout only" and needle in out["alt_error"]
+    assert "AFTER the first layout had been measured" in r.stderr
+
+
 def test_supervisor_rank_death_during_bring_up_is_a_transport_failure(tmp_path):
     """A rank that dies between "started" and "up" (ncclCommInitRank returned an error on one side) leaves its peers blocked:
     they are killed after the grace period and the fresh set takes the torch transport."""
@@ -217,11 +228,34 @@ def test_single_rank_rccl_exchange_path_through_bench():
 def test_four_rank_rehearsals_on_one_gpu():
     """--gpus 4 (the driver's next point after 2): `tiny` has 2 heads, so four ranks cannot be pure Ulysses -- the bench picks the
     Ulysses 2 x ring 2 hybrid itself, as the CLI does for the 1.3B model on 8 GPUs; --cfg-degree 2 gives two Ulysses pairs."""
+    r = _run(["--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline", "--single-layout"],
+             timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "ulysses-sp4 (ulysses 2 x ring 2)" and "alt" not in out
+    assert out["outputs_finite"] is True and out["rccl_observed"]["sp"]["ranks"] == 4 and out["rccl_observed"]["sp"]["ring_degree"] == 2
+    # the driver's own command line (round 4): Ulysses over the four ranks FIRST, then the CFG pair on two Ulysses pairs in the same run;
+    # the faster is the headline, the other sits under "alt" (the third layout, the reference's Ulysses 2 x ring N/2, needs a head count
+    # that divides by N: not this 2-head model)
     r = _run(["--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"], timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip())
-    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "ulysses-sp4 (ulysses 2 x ring 2)"
-    assert out["outputs_finite"] is True and out["rccl_observed"]["sp"]["ranks"] == 4 and out["rccl_observed"]["sp"]["ring_degree"] == 2
+    both = {out["config"]["parallelism"]} | {a["parallelism"] for a in out["alt"]}
+    assert both == {"ulysses-sp4 (ulysses 2 x ring 2)", "cfg2 x ulysses-sp2"} and len(out["alt"]) == 1
+    assert out["outputs_finite"] is True and all(a["outputs_finite"] for a in out["alt"]) and "alt_error" not in out
+    # a model whose heads divide by 4: all three layouts in one run, the third being the reference's documented Ulysses 2 x ring N/2
+    r = _run(["--gpus", "4", "--workload", "tiny4h", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"], timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    three = {out["config"]["parallelism"]} | {a["parallelism"] for a in out["alt"]}
+    assert three == {"ulysses-sp4", "cfg2 x ulysses-sp2", "ulysses-sp4 (ulysses 2 x ring 2)"}, three
+    assert out["outputs_finite"] is True and all(a["outputs_finite"] for a in out["alt"])
+    # ... and none of them when the run is already old (the time mark): the first layout alone, the others listed as skipped
+    r = _run(["--gpus", "4", "--workload", "tiny4h", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"],
+             env={"VC_BENCH_ALT_DEADLINE": "0"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip())
+    assert out["config"]["parallelism"] == "ulysses-sp4" and "alt" not in out and len(out["alt_skipped"]) == 2
     r = _run(["--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
               "--cfg-degree", "2"], timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -463,12 +463,24 @@ def test_cfg1_full_depth_forward_vs_oracle_and_four_step_sampler():
     torch.cuda.synchronize()
     Wf = {k: v.float() for k, v in W.items()}
     args = (Wf, cfg, x.float(), t, geo.float(), [c.float() for c in ctx], L)
-    want = O.forward(*args)
+    # The oracle's fp32 output for exactly these seeded weights and inputs is a recorded fixture (tests/golden/make_golden_cfg1_oracle.py:
+    # 60-100 s of CPU time per run otherwise, a sixth of the GPU suite); the check sums prove the test regenerated the same numbers.
+    # VC_TEST_RECOMPUTE_ORACLE=1 runs the oracle instead.
+    gold = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_full_depth_oracle.safetensors"))
+    same_inputs = (float(gold["x_sum"]) == float(x.float().sum()) and float(gold["geo_sum"]) == float(geo.float().sum()) and
+                   float(gold["w_sum"]) == float(sum(v.float().sum() for v in W.values())))
+    if os.environ.get("VC_TEST_RECOMPUTE_ORACLE") == "1" or not same_inputs:
+        want = O.forward(*args)
+        if same_inputs:
+            assert rel(want, gold["want"]) < 1e-5, "the recorded oracle output no longer matches the oracle"    # thread count changes fp32 sum order
+    else:
+        want = gold["want"]
     e_hip = rel(got, want)
     # the oracle's own bf16-rounding mode on these seeded inputs: 0.01444 (recorded; a second full-depth CPU forward costs 85 s of the
     # suite -- VC_TEST_RECOMPUTE_BF16_REF=1 recomputes it)
     e_ref = rel(O.forward(*args, mode="bf16"), want) if os.environ.get("VC_TEST_RECOMPUTE_BF16_REF") == "1" else 0.01444
-    print(f"cfg-1 full depth (30+15 blocks): engine rel L2 {e_hip:.4g}; bf16-reference rel L2 {e_ref:.4g}")
+    print(f"cfg-1 full depth (30+15 blocks): engine rel L2 {e_hip:.4g}; bf16-reference rel L2 {e_ref:.4g}"
+          f"{'' if same_inputs else ' (fixture inputs differ: oracle recomputed)'}")
     assert torch.isfinite(got.float()).all()
     assert e_hip < 3e-2 and e_hip < 3 * e_ref + 2e-3
 
@@ -800,6 +812,87 @@ def test_two_expert_sampler_switches_at_the_boundary(model):
     want, _ = run(high if hi[0] else low, callback=swap)
     assert torch.equal(mixed, want)
     assert torch.isfinite(mixed.float()).all() and not torch.equal(mixed, only_low) and not torch.equal(mixed, only_high)
+
+
+def test_two_expert_pipeline_with_teacache_is_reusable(model):
+    """Round-3 advisor finding: with two experts each TeaCache only counts the steps ITS expert ran, so the reference's own reset
+    (cnt == num_steps at the end of forward, VC.py:438-441) never fires; a second video through the same pipeline then started past
+    num_skip_start_steps, could skip at step 0 and re-add the PREVIOUS video's residual.  The sampler now resets every expert's gate and
+    the engines' residual slots at the start of a call: call 2 must equal what a fresh set of gates gives."""
+    from versecrafter_amd.models import VerseCrafterWanTransformer3DModel
+    from versecrafter_amd.pipeline import WanVerseCrafterPipeline
+    from versecrafter_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    cfg = O.Config(**TINY)
+    low = model
+    high = VerseCrafterWanTransformer3DModel(**TINY)
+    high.load_state_dict(O.random_weights(cfg, 23))
+    high = high.to(torch.bfloat16).to("cuda")
+    g = torch.Generator().manual_seed(8)
+    T, h, w = 3, 8, 12
+    lats = [torch.randn(1, 16, T, h, w, generator=g).bfloat16().cuda() for _ in range(2)]
+    geo = torch.randn(64, T, h, w, generator=g).bfloat16().cuda()
+    msk = (torch.rand(64, T, h, w, generator=g) < 0.5).to(torch.bfloat16).cuda()
+    pe, ne = torch.randn(33, cfg.text_dim, generator=g).bfloat16().cuda(), torch.randn(20, cfg.text_dim, generator=g).bfloat16().cuda()
+    steps = 6
+    coeff = [0.0, 0.0, 0.0, 1.0, 0.0]                      # accumulated distance = sum of relative L1 changes: far below the threshold
+
+    def gates():
+        for m in (low, high):
+            m.enable_teacache(coeff, steps, 1e6, num_skip_start_steps=1, offload=False)     # skips every step it may skip
+
+    def call(pipe, lat):
+        out = pipe(prompt_embeds=[pe], negative_prompt_embeds=[ne], height=h * 8, width=w * 8, geoada_latents=[geo], mask_latents=[msk],
+                   num_inference_steps=steps, guidance_scale=5.0, shift=12, latents=lat.clone(), output_type="latent", boundary=0.875).videos
+        torch.cuda.synchronize()
+        return out
+    try:
+        gates()
+        pipe = WanVerseCrafterPipeline(transformer=low, transformer_2=high, scheduler=FlowUniPCMultistepScheduler(shift=1))
+        first = call(pipe, lats[0])
+        second = call(pipe, lats[1])                       # same pipeline, same gates, another video
+        assert 0 < sum(pipe._high_noise_steps) < steps
+        gates()                                            # fresh gates (and the pipeline drops the engines' residuals itself)
+        fresh = call(WanVerseCrafterPipeline(transformer=low, transformer_2=high, scheduler=FlowUniPCMultistepScheduler(shift=1)), lats[1])
+        assert torch.isfinite(second.float()).all() and torch.equal(second, fresh)
+        assert not torch.equal(first, second)
+        # the gates really skipped: the low-noise expert's counter shows more forwards than computed steps would leave it at
+        assert low.teacache.cnt > 0 and high.teacache.cnt > 0
+    finally:
+        low.disable_teacache()
+        high.disable_teacache()
+
+
+def test_fp8_attention_mode(model):
+    """enable_fp8_attention (this build; BASELINE config 5's dtype): the blocks' SELF-attention through csrc/attention_fp8.hip.  The output
+    moves away from the bf16 forward by the quantisation error (tiny model: < 8e-2 rel L2, both ways of making the weights' bytes), is
+    deterministic, a graph replay equals the eager call, and switching the mode off restores the bf16 forward bit for bit."""
+    g = torch.Generator().manual_seed(22)
+    T, h, w = 3, 8, 12
+    x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+    t = torch.tensor([640.0, 640.0]).cuda()
+    ref = model(x, t, geo, ctx, 72).clone()
+    try:
+        outs = {}
+        for pmode in (1, 0):
+            model.enable_fp8_attention(True, pmode)
+            a = model(x, t, geo, ctx, 72).clone()
+            b = model(x, t, geo, ctx, 72).clone()
+            c = model(x, t, geo, ctx, 72).clone()
+            assert torch.equal(a, b) and torch.equal(a, c) and torch.isfinite(a.float()).all()
+            e = rel(a, ref)
+            print(f"tiny model, fp8 self-attention pmode {pmode} vs bf16: rel L2 {e:.4g}")
+            assert 1e-4 < e < 8e-2, e
+            outs[pmode] = a
+        assert not torch.equal(outs[0], outs[1])
+        model.enable_fp8_linear()                          # both fp8 modes together
+        d = model(x, t, geo, ctx, 72)
+        assert torch.isfinite(d.float()).all() and rel(d, ref) < 0.12
+    finally:
+        model.enable_fp8_linear(False)
+        model.enable_fp8_attention(False)
+    assert torch.equal(model(x, t, geo, ctx, 72), ref)
 
 
 def test_fp8_linear_mode(model):

@@ -47,7 +47,8 @@ constexpr int KPITCH = 144, VPITCH = 80;          // row pitch of the K / V^T ti
 constexpr int KTILE = KT * KPITCH, VTILE = 128 * VPITCH, STILE = 256;      // bytes of a K image (9 KiB), a V^T image (10 KiB), a scale tile
 constexpr int NST = 4;                            // LDS ring depth
 constexpr int F8_KST = 0, F8_VST = NST * KTILE, F8_KSC = F8_VST + NST * VTILE, F8_VSC = F8_KSC + NST * STILE;
-constexpr int F8_LDS = F8_VSC + NST * STILE;      // 78 KiB
+constexpr int F8_ONES = F8_VSC + NST * STILE;     // 32 bytes of e4m3 1.0: the A operand of the row-sum MFMA, read like a fragment (broadcast)
+constexpr int F8_LDS = F8_ONES + 64;              // 78 KiB
 typedef i32x8 __attribute__((aligned(16))) i32x8_a16;
 constexpr float K1 = 65535.0f / 8.0f;             // raw accumulator units -> log2 units
 constexpr float DEFER_T = 8.0f;                   // a row's reference follows its maximum once it is 2^8 behind (as the bf16 kernel)
@@ -209,9 +210,21 @@ VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_unifo
 #ifndef F8_POST
 #define F8_POST ""
 #endif
+#ifndef F8_ABLATE
+#define F8_ABLATE 0         // timing-only builds (WRONG results): 1 no DMA wait / barrier, 2 no LDS-DMA issue, 3 both, 4 no MFMA, 5 no conversion of P,
+#endif                      // 6 no fragment reads from LDS (tools/ablate_attn_fp8.sh)
+#ifndef F8_STAGGER
+#define F8_STAGGER 1        // waves 4-7 run the two phases of a beat in the other order (0: all eight waves in step)
+#endif
 #ifndef F8_PRE
 #define F8_PRE "s_nop 1\n\t"
 #endif
+#if F8_ABLATE == 4
+#define F8_MFMA(acc, a, b, sa, sb, OPS) asm volatile("" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_NOP(acc, a, b, sa, sb, OPS) asm volatile("" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_ZERO(acc, a, b, sa, sb, OPS) asm volatile("" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#define F8_MFMA_ZERO_NOP(acc, a, b, sa, sb, OPS) asm volatile("" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#else
 #define F8_MFMA(acc, a, b, sa, sb, OPS) \
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS F8_POST : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
 #define F8_MFMA_NOP(acc, a, b, sa, sb, OPS) \
@@ -220,6 +233,7 @@ VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_unifo
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 " OPS F8_POST : "=&v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
 #define F8_MFMA_ZERO_NOP(acc, a, b, sa, sb, OPS) \
     asm volatile(F8_PRE "v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 " OPS F8_POST : "=&v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb))
+#endif
 #define F8_MFMA_SETTLE4(a0, a1, a2, a3) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 
 template <int PMODE>
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     const int nt = (k_len + KT - 1) / KT;
     const bool tail_partial = (k_len & (KT - 1)) != 0;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
-    const unsigned lane16 = (unsigned)(wave * 1024 + lane * 16), lane4 = (unsigned)(lane * 4);
+    const unsigned lane16 = (unsigned)(lane * 16);     // the wave's 1-KiB piece is selected through the scalar base
 
     // One wave-instruction of LDS-DMA moves 1 KiB; a K image is 9 such pieces, a V^T image 10: wave w moves piece w of each, wave 0 also
     // piece 8 of both, wave 1 piece 9 of V^T.  Loads of one loop iteration t (issued right after its barrier), in THIS order: the extras
@@ -257,20 +271,23 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     auto stage_k = [&](int tile, int slot, bool extras) {
         const char* src = k8 + (int64_t)tile * KTILE;
         const unsigned dst = lds0 + F8_KST + slot * KTILE;
-        if (extras) { if (wave == 0) f8_glds16(lane * 16, src + 8192, __builtin_amdgcn_readfirstlane(dst + 8192)); }
-        else f8_glds16(lane16, src, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
+        if (extras) { if (wave == 0) f8_glds16(lane16, src + 8192, __builtin_amdgcn_readfirstlane(dst + 8192)); }
+        else f8_glds16(lane16, src + wave * 1024, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
     };
     auto stage_v = [&](int tile, int slot, bool extras) {
         const char* src = v8 + (int64_t)tile * VTILE;
         const unsigned dst = lds0 + F8_VST + slot * VTILE;
-        if (extras) { if (wave < 2) f8_glds16(lane * 16, src + 8192 + wave * 1024, __builtin_amdgcn_readfirstlane(dst + 8192 + wave * 1024)); }
-        else f8_glds16(lane16, src, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
+        if (extras) { if (wave < 2) f8_glds16(lane16, src + 8192 + wave * 1024, __builtin_amdgcn_readfirstlane(dst + 8192 + wave * 1024)); }
+        else f8_glds16(lane16, src + wave * 1024, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
     };
+    // lane * 4 is derived from lane * 16 where it is needed, by an instruction hipcc cannot hoist out of the tile loop: as a loop invariant
+    // it (and the LDS addresses built on it) ended up spilled, and a spill reload inside the loop waits vmcnt(0) -- draining the LDS-DMA ring
+    auto lane4_now = [&]() { unsigned a; asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(a) : "v"(lane16)); return a; };
     auto stage_ks = [&](int tile, int slot) {
-        if (wave == 0) f8_glds4(lane4, ks + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_KSC + slot * STILE));
+        if (wave == 0) f8_glds4(lane4_now(), ks + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_KSC + slot * STILE));
     };
     auto stage_vs = [&](int tile, int slot) {
-        if (wave == 1) f8_glds4(lane4, vs + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_VSC + slot * STILE));
+        if (wave == 1) f8_glds4(lane4_now(), vs + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_VSC + slot * STILE));
     };
     auto issue = [&](int t) {
         const int tks = min(t + 2, nt - 1), tvs = min(t + 1, nt - 1), tk = min(t + 3, nt - 1), tv = min(t + 2, nt - 1);
@@ -309,10 +326,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     }
     // fragment addresses: K row kb*32 + r, bytes (2s+h)*32 .. +31; V^T row db*32 + r, bytes 32h .. +31 (pitches 144 / 80: no swizzle)
     const unsigned koff = (unsigned)(r * KPITCH + 32 * h), voff = (unsigned)(r * VPITCH + 32 * h);
-    i32x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = 0x38383838;             // e4m3 1.0
-    const int unit = 0x7F7F7F7F;
+    if (tid < 8) *(int*)(smem + F8_ONES + tid * 4) = 0x38383838;  // e4m3 1.0 (visible after the prologue's barrier)
+    if (tid == 8) *(int*)(smem + F8_ONES + 32) = 0x7F7F7F7F;      // and the unit E8M0 scale that goes with it
 
     f32x16 O[4];
 #pragma unroll
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
 
     auto qk = [&](int t, f32x16 (&S)[2]) {                        // S(t) = K(t) Q^T : 4 MFMAs
         const char* kbuf = smem + F8_KST + (t & 3) * KTILE;
-        const int ksc = *(const int*)(smem + F8_KSC + (t & 3) * STILE + lane * 4);
+        const int ksc = *(const int*)(smem + F8_KSC + (t & 3) * STILE + lane4_now());
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             i32x8 kf[2];
@@ -367,18 +382,37 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     m_tile = row_max(Sa);
     m_new = m_tile;
 
-    // ONE body instance per S-buffer role, run-time flags for "a next tile exists" and "it is the masked last one" (wave-uniform
-    // branches).  The bf16 kernel's specialised tail instances are not an option here: hipcc spills accumulators around them, and a
-    // spill store that follows an inline-asm MFMA reads its result before the matrix pipe has written it (the compiler does not know
-    // the statement is an MFMA) -- found as wrong outputs for short key sequences; tests/test_build_resources.py requires 0 scratch.
-    auto body = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
+    // A tile's work is two phases (below).  ONE instance of each per S-buffer role, run-time flags for "a next tile exists" and "it is the
+    // masked last one" (wave-uniform branches): the bf16 kernel's specialised tail instances are not an option here -- hipcc spills
+    // accumulators around them, and a spill store that follows an inline-asm MFMA reads its result before the matrix pipe has written it
+    // (the compiler does not know the statement is an MFMA); found as wrong outputs for short key sequences; tests/test_build_resources.py
+    // requires 0 scratch.
+    //   phase 1 (t): [deferred rescale] ; exponent of P(t) ; MFMA S(t+1) = K(t+1) Q^T (4)  ||  VALU: the e4m3 bytes of P(t)
+    //   phase 2 (t): MFMA row sum, O += V(t)^T P(t)^T (1 + 4)                                 ||  VALU: row maximum of S(t+1)
+    // The nine MFMAs are inline asm, which hipcc keeps in order but does not interleave by itself, so the VALU / LDS work is placed BETWEEN
+    // them by hand: a quarter of P(t)'s conversion (14 VALU) and the fragment reads of the MFMA after next behind each QK^T MFMA, a quarter
+    // of the row maximum behind each PV MFMA.  An accumulator is read only after a LATER group of MFMAs of this wave has been issued.
+    // Waves 4-7 run the two phases of a beat (= the stretch between two workgroup barriers) in the OTHER order -- phase 2 of the previous
+    // tile, then phase 1 of this one -- so that on every SIMD one wave is in its VALU-heavy QK^T phase (and its serial head: barrier, DMA
+    // issue, rescale test) while its partner feeds the matrix pipe from the VALU-light PV phase (MI355X_MICROARCH.md "Two waves per SIMD",
+    // item 9; same per-row operation order, so both halves give bit-identical rows).
+    // Fragment reads sit one MFMA gap ahead of the MFMA that takes them.  (Reading a whole phase ahead -- all K fragments behind the beat's
+    // barrier, the V^T fragments in the QK^T gaps, 243 VGPRs -- was measured and is SLOWER: 23.2 ms against 21.1 ms at the bench shape,
+    // profiles/r04_attn_fp8_ablate.txt; the LDS round trip is not what the waves wait for.)
+    i32x8 pf;
+    int pscale = 0;
+#define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto beat_head = [&](int t) {
+        F8_FENCE();
+        if (F8_ABLATE != 1 && F8_ABLATE != 3) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // all but the two youngest pieces: K(t+1), V(t), their scales are in LDS
+            __builtin_amdgcn_s_barrier();                         // ... for every wave; and every wave is past its reads of the slots refilled now
+        }
+        F8_FENCE();
+        if (F8_ABLATE != 2 && F8_ABLATE != 3) issue(t);
+    };
+    auto phase1 = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
         const bool MORE = t + 1 < nt;
-        const bool MASK = MORE && tail_partial && (t + 2 == nt);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // all but the two youngest pieces: K(t+1), V(t), their scales are in LDS
-        __builtin_amdgcn_s_barrier();                             // ... for every wave; and every wave is past QK(t), PV(t-1)
-        __builtin_amdgcn_sched_barrier(0);
-        issue(t);
         // deferred rescale (as attn_fwd_pipe_kernel): the row's reference follows its running maximum only after 2^DEFER_T
         {
             const bool moved = (m_new - m_run) * K1 > DEFER_T;
@@ -396,72 +430,150 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
         }
         // block scale of P(t): 2^(et - 8), et = ceil(log2 of the tile's largest weight against the reference) (<= DEFER_T)
         const float et = fmaxf(__builtin_ceilf((m_tile - m_run) * K1), -100.f);
-        const int pscale = 119 + (int)et;
-        // ---- phase 1: MFMA S(t+1)  ||  VALU: the e4m3 bytes of P(t) ----
-        if (MORE) qk(t + 1, Sn);
-        i32x8 pf;
-        if (PMODE == 1) {
-            // byte = round(8 (log2 units of s - reference - et + 8) + 56) = round(65535 (s - m_run) + 120 - 8 et): v_cvt_pknorm_u16_f32
-            // computes round(65535 clamp(x, 0, 1)); the result is < 256, the low bytes of the two halves are gathered by v_perm_b32
-            const float kc = (120.f - 8.f * et) * (1.0f / 65535.0f) - m_run;
+        pscale = 119 + (int)et;
+        const float kc = PMODE == 1 ? (120.f - 8.f * et) * (1.0f / 65535.0f) - m_run : 8.f - et - m_run * K1;
+        // one dword of P(t): four weights.  `k` is the gap's own copy of the constant (an opaque copy made BEHIND the MFMA that opens the
+        // gap), and the gap ends in a statement that consumes the dwords it produced: the conversion can neither rise above the gap's
+        // MFMA nor sink below the next one (sched_barrier alone does not hold it: the adds are emitted before the first fence otherwise)
+        auto pconv = [&](int kb, int i, float k) -> int {
+            if (PMODE == 1) {
+                // byte = round(8 (log2 units of s - reference - et + 8) + 56) = round(65535 (s - m_run) + 120 - 8 et): v_cvt_pknorm_u16_f32
+                // computes round(65535 clamp(x, 0, 1)); the result is < 256, the low bytes of the two halves are gathered by v_perm_b32
+                const u16x2 u01 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i] + k, Sc[kb][4 * i + 1] + k);
+                const u16x2 u23 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i + 2] + k, Sc[kb][4 * i + 3] + k);
+                return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, u23), __builtin_bit_cast(unsigned, u01), 0x06040200u);
+            } else {
+                float pe[4];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u16x2 u01 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i] + kc, Sc[kb][4 * i + 1] + kc);
-                    const u16x2 u23 = __builtin_amdgcn_cvt_pknorm_u16(Sc[kb][4 * i + 2] + kc, Sc[kb][4 * i + 3] + kc);
-                    pf[kb * 4 + i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, u23), __builtin_bit_cast(unsigned, u01), 0x06040200u);
-                }
+                for (int j = 0; j < 4; ++j) pe[j] = __builtin_amdgcn_exp2f(Sc[kb][4 * i + j] * K1 + k);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(pe[0], pe[1], 0, false);
+                return __builtin_amdgcn_cvt_pk_fp8_f32(pe[2], pe[3], w, true);
+            }
+        };
+        auto pgap = [&](int kb, int i0) {                         // dwords i0, i0 + 1 of half kb
+            if (F8_ABLATE == 5) { pf[kb * 4 + i0] = __float_as_int(Sc[kb][4 * i0]); pf[kb * 4 + i0 + 1] = __float_as_int(Sc[kb][4 * i0 + 4]); return; }
+            float k = kc;
+            asm volatile("" : "+v"(k));
+            const int w0 = pconv(kb, i0, k), w1 = pconv(kb, i0 + 1, k);
+            asm volatile("" :: "v"(w0), "v"(w1));
+            pf[kb * 4 + i0] = w0;
+            pf[kb * 4 + i0 + 1] = w1;
+        };
+        if (MORE) {
+            const char* kbuf = smem + F8_KST + ((t + 1) & 3) * KTILE;
+            const int ksc = *(const int*)(smem + F8_KSC + ((t + 1) & 3) * STILE + lane4_now());
+            const i32x8 k00 = *(const i32x8_a16*)(kbuf + koff), k01 = *(const i32x8_a16*)(kbuf + koff + 64);
+            F8_FENCE();
+            F8_MFMA_ZERO(Sn[0], k00, qf[0], ksc, qsc, F8_OPS_00);
+            const i32x8 k10 = *(const i32x8_a16*)(kbuf + 32 * KPITCH + koff);
+            pgap(0, 0);
+            F8_FENCE();
+            F8_MFMA(Sn[0], k01, qf[1], ksc, qsc, F8_OPS_12);
+            const i32x8 k11 = *(const i32x8_a16*)(kbuf + 32 * KPITCH + koff + 64);
+            pgap(0, 2);
+            F8_FENCE();
+            F8_MFMA_ZERO(Sn[1], k10, qf[0], ksc, qsc, F8_OPS_20);
+            pgap(1, 0);
+            F8_FENCE();
+            F8_MFMA(Sn[1], k11, qf[1], ksc, qsc, F8_OPS_32);
+            pgap(1, 2);
+            F8_FENCE();
         } else {
-            const float ka = 8.f - et - m_run * K1;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float pe[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pe[j] = __builtin_amdgcn_exp2f(Sc[kb][4 * i + j] * K1 + ka);
-                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(pe[0], pe[1], 0, false);
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(pe[2], pe[3], w, true);
-                    pf[kb * 4 + i] = w;
-                }
+            pgap(0, 0); pgap(0, 2); pgap(1, 0); pgap(1, 2);
+            F8_FENCE();
         }
-        // ---- phase 2: MFMA O += V(t)^T P(t)^T, l += 1 P(t)^T  ||  VALU: row maximum of S(t+1) ----
+    };
+    auto phase2 = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
+        const bool MORE = t + 1 < nt;
+        const bool MASK = MORE && tail_partial && (t + 2 == nt);
+        const char* vbuf = smem + F8_VST + (t & 3) * VTILE;
+        i32x8 vf[4];
+        const int vsc = *(const int*)(smem + F8_VSC + (t & 3) * STILE + lane4_now());
+        vf[0] = *(const i32x8_a16*)(vbuf + voff);
+        // PV gaps: a quarter of S(t+1)'s row maximum each, unconditionally (no branch, no copies at merge points: on the last tile and on the
+        // masked one -- which takes its maximum again behind the mask -- the result is simply not used)
+        float mxa = -1e30f;
+        // the tile's row sum FIRST, into the registers of S(t) (dead: P(t) has been packed): 1^T P^T has 32 equal rows, element 0 is
+        // added to the running sum once the four MFMAs behind it have been issued
         {
-            const char* vbuf = smem + F8_VST + (t & 3) * VTILE;
-            const int vsc = *(const int*)(smem + F8_VSC + (t & 3) * STILE + lane * 4);
-            i32x8 vf[4];
-#pragma unroll
-            for (int db = 0; db < 4; ++db) vf[db] = *(const i32x8_a16*)(vbuf + db * (32 * VPITCH) + voff);
-            // the tile's row sum FIRST, into the registers of S(t) (dead: P(t) has been packed): 1^T P^T has 32 equal rows, element 0 is
-            // added to the running sum once the four MFMAs behind it have been issued (in-order matrix pipe: it has completed by then)
+            const i32x8 ones = *(const i32x8_a16*)(smem + F8_ONES);            // every lane the same 32 bytes: a broadcast read, no register kept
+            const int unit = *(const int*)(smem + F8_ONES + 32);
+            F8_FENCE();
             F8_MFMA_ZERO_NOP(Sc[0], ones, pf, unit, pscale, F8_OPS_00);
-            F8_MFMA(O[0], vf[0], pf, vsc, pscale, F8_OPS_00);
-            F8_MFMA(O[1], vf[1], pf, vsc, pscale, F8_OPS_10);
-            F8_MFMA(O[2], vf[2], pf, vsc, pscale, F8_OPS_20);
-            F8_MFMA(O[3], vf[3], pf, vsc, pscale, F8_OPS_30);
         }
-        // S(t+1) and the tile sum were written by MFMAs issued BEFORE the last four (the matrix pipe is in order): readable from here on
+        vf[1] = *(const i32x8_a16*)(vbuf + 32 * VPITCH + voff);
+        asm volatile("" : "+v"(Sn[0]));                           // written at least two MFMAs before the one just issued
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, Sn[0][e]);
+        asm volatile("" : "+v"(mxa));
+        F8_FENCE();
+        F8_MFMA(O[0], vf[0], pf, vsc, pscale, F8_OPS_00);
+        vf[2] = *(const i32x8_a16*)(vbuf + 64 * VPITCH + voff);
+#pragma unroll
+        for (int e = 8; e < 16; ++e) mxa = fmaxf(mxa, Sn[0][e]);
+        asm volatile("" : "+v"(mxa));
+        F8_FENCE();
+        F8_MFMA(O[1], vf[1], pf, vsc, pscale, F8_OPS_10);
+        vf[3] = *(const i32x8_a16*)(vbuf + 96 * VPITCH + voff);
+        asm volatile("" : "+v"(Sn[1]));                           // at least three MFMAs behind the last QK^T one
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, Sn[1][e]);
+        asm volatile("" : "+v"(mxa));
+        F8_FENCE();
+        F8_MFMA(O[2], vf[2], pf, vsc, pscale, F8_OPS_20);
+#pragma unroll
+        for (int e = 8; e < 16; ++e) mxa = fmaxf(mxa, Sn[1][e]);
+        asm volatile("" : "+v"(mxa));
+        F8_FENCE();
+        F8_MFMA(O[3], vf[3], pf, vsc, pscale, F8_OPS_30);
+        F8_FENCE();
         asm volatile("" : "+v"(Sc[0]));
         l_run += Sc[0][0];
-        if (MORE) asm volatile("" : "+v"(Sn[0]), "+v"(Sn[1]));
         if (MORE) {
-            if (MASK) mask_tail(Sn, t + 1);
-            m_tile = row_max(Sn);
+            if (MASK) {
+                mask_tail(Sn, t + 1);
+                m_tile = row_max(Sn);
+            } else {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxa), __float_as_uint(mxa), false, false);
+                m_tile = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             m_new = fmaxf(m_new, m_tile);
         }
     };
-    for (int t = 0; t < nt; t += 2) {
-        body(t, Sa, Sb);
-        if (t + 1 < nt) body(t + 1, Sb, Sa);
+#undef F8_FENCE
+    // one loop for both halves of the workgroup (wave-uniform branches on `stag`); beat t = [barrier t .. barrier t+1):
+    //   waves 0-3: phase1(t) phase2(t)         waves 4-7: phase2(t-1) phase1(t), and phase2(nt-1) behind the last beat
+    const bool stag = F8_STAGGER != 0 && wave >= 4;
+    for (int t = 0; t <= nt; t += 2) {
+        if (t < nt) beat_head(t);
+        if (stag && t > 0) phase2(t - 1, Sb, Sa);
+        if (t < nt) {
+            phase1(t, Sa, Sb);
+            if (!stag) phase2(t, Sa, Sb);
+        }
+        if (t + 1 <= nt) {
+            if (t + 1 < nt) beat_head(t + 1);
+            if (stag && t < nt) phase2(t, Sa, Sb);
+            if (t + 1 < nt) {
+                phase1(t + 1, Sb, Sa);
+                if (!stag) phase2(t + 1, Sb, Sa);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may still be landing in LDS when the workgroup retires
     F8_MFMA_SETTLE4(O[0], O[1], O[2], O[3]);
 
+    // Epilogue.  The lane's row and half are derived AGAIN here, from an instruction hipcc cannot move above the loop: kept alive across it
+    // they were the values it chose to spill (the kernel must have no scratch at all: tests/test_build_resources.py).
+    unsigned lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int r_e = (int)(lane_e & 31u), h_e = (int)(lane_e >> 5);
+    const int q_row_e = qb * 256 + wave * 32 + r_e;
+    const int q_row_ce = q_row_e < p.Lq ? q_row_e : p.Lq - 1;
     const float inv = 1.0f / l_run;
     const bool wide = (((p.o_ts | p.o_hs | p.o_bs) & 7) == 0) && (((uintptr_t)p.out & 15) == 0);
     if (wide) {
-        bf16_t* orow = op + (int64_t)q_row_c * p.o_ts + 8 * h;
+        bf16_t* orow = op + (int64_t)q_row_ce * p.o_ts + 8 * h_e;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -472,10 +584,10 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
                 const uint2 pa = pack4(va), pb = pack4(vb);
                 const auto sx = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
-                if (q_row < p.Lq) *(uint4*)(orow + db * 32 + 16 * j) = uint4{sx[0], sy[0], sx[1], sy[1]};
+                if (q_row_e < p.Lq) *(uint4*)(orow + db * 32 + 16 * j) = uint4{sx[0], sy[0], sx[1], sy[1]};
             }
-    } else if (q_row < p.Lq) {
-        bf16_t* orow = op + (int64_t)q_row * p.o_ts + 4 * h;
+    } else if (q_row_e < p.Lq) {
+        bf16_t* orow = op + (int64_t)q_row_e * p.o_ts + 4 * h_e;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll

@@ -1572,7 +1572,7 @@ int vc_op_gemm_bf16(const void* A, int64_t lda, const void* Wt, int64_t ldw, voi
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
     p.epilogue = epilogue; p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_bstride = gate_bstride;
     p.rows_per_batch = rows_per_batch; p.hint = hint; p.ldh = ldh; p.hint_scale = hint_scale; p.valid_rows = -1;
-    p.a_rows_padded = tile == 4 || tile == 5;     // tiles 4, 5 (tests / tuning): the caller promises A is readable up to the next 256 rows
+    p.a_rows_padded = tile == 4 || tile == 5 || tile == 6;     // tiles 4, 5, 6 (tests / tuning): the caller promises A is readable up to the next 256 rows
     p.tile = tile;
     return vc_launch_gemm(p, (hipStream_t)stream);
 }

@@ -345,8 +345,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
     const int group = id / width;
     const int first_m = group * GROUP_M;
     const int gsz = min(nTm - first_m, GROUP_M);
-    const int tm = first_m + (id % width) % gsz;
+    int tm = first_m + (id % width) % gsz;
     int tn = (id % width) / gsz;
+    if (p.tile_map == 1) {
+        // A/B of the round-3 review's proposal (tile id 6, tools only; same tiles, same arithmetic, bit-identical C): the eight XCDs walk
+        // the SAME super-band of 64 tile rows -- XCD x takes rows 64 s + 8 x .. + 7 of super-band s, all tile columns -- instead of eight
+        // bands 32 tile rows apart (nTm % 64 == 0: the launcher checks)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int sb = j / width, q = j - sb * width;
+        tm = 64 * sb + 8 * x + (q & 7);
+        tn = q >> 3;
+    }
     const int nTn1 = p.ngroups > 1 ? nTn / p.ngroups : nTn;
     const int grp = tn / nTn1;
     tn -= grp * nTn1;
@@ -1046,8 +1055,15 @@ int vc_launch_gemm(const VcGemmParams& p, hipStream_t stream) {
     if (p.hint) epi_ok = epi_ok && p.ldh % 8 == 0 && ((uintptr_t)p.hint & 15) == 0;
     for (int g = 1; g < p.ngroups; ++g) epi_ok = epi_ok && ((uintptr_t)p.Cg[g - 1] & 15) == 0;
     if (big && rows_ok && epi_ok && p.N % 256 == 0 && p.K % 128 == 0 && p.lda * 512 < (1ll << 31) && p.ldw * 512 < (1ll << 31) &&
-        (p.tile == 0 || p.tile == 4 || p.tile == 5))
+        (p.tile == 0 || p.tile == 4 || p.tile == 5 || p.tile == 6)) {
+        if (p.tile == 6) {          // ping-pong kernel under the "shared super-band" tile map (A/B tool only)
+            if (((p.M + 255) / 256) % 64) return VC_E_UNSUPPORTED;
+            VcGemmParams q = p;
+            q.tile_map = 1;
+            return launch_pp(q, stream);
+        }
         return p.tile == 5 ? launch_sw(p, stream) : launch_pp(p, stream);
+    }
     // operands below 4 GiB (every shape of the engine): LDS-DMA with 32-bit lane offsets against a scalar base
     const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
     if (big && fits32 && p.tile != 3) return launch_cfg<GemmCfg<256, 256, 2, 4>, true>(p, stream);

@@ -38,6 +38,7 @@ struct VcGemmParams {
     int a_rows_padded;               // rows of A up to the next multiple of 256 are readable (engine workspace)
     int valid_rows;                  // >= 0: rows with (m % rows_per_batch) >= valid_rows are written as 0; < 0: off
     int tile;                        // kernel selection for tests / tuning (0 = auto; see vc_launch_gemm)
+    int tile_map;                    // ping-pong kernel: 0 = XCD-contiguous bands (production), 1 = all XCDs on one 64-row super-band (A/B, tile id 6)
     // fp8 operands (BASELINE config 5's dtype; block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales): A and W hold OCP
     // e4m3 bytes ([M, K] / [N, K]; lda / ldw in elements = bytes), C = (A W^T) * a_scale[m] * w_scale[n], then the epilogue as for bf16.
     // Ping-pong kernel only: M padded / % 256, N % 256, K % 256.

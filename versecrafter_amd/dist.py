@@ -27,6 +27,8 @@ from . import _lib
 _SP_GROUP = None
 _BP_GROUP = None       # batch-parallel group (the samples of a CFG pair on different ranks); None = off
 _RING_DEGREE = 1       # the ring degree the caller asked for (set_multi_gpus_devices); see choose_ring_degree
+STALLED = False        # set when a communicator rendezvous did not return (SequenceParallelStall): a helper thread is still inside
+                       # ncclCommInitRank with the engine handle -- nothing may destroy that handle any more, the process has to end
 _RING_AS_GIVEN = False # True: a valid requested ring degree is used as it is (the reference's documented layout), never folded into Ulysses
 
 
@@ -357,7 +359,10 @@ def _group_has_rccl(group) -> bool:
 
 
 class SequenceParallelStall(RuntimeError):
-    """The blocking rendezvous of the engine's RCCL communicators did not return within its deadline."""
+    """The blocking rendezvous of the engine's RCCL communicators did not return within its deadline.  The helper thread is still inside
+    ncclCommInitRank with the engine handle: no clean-up may touch that handle (the model's __del__ skips vc_destroy once `STALLED` is
+    set); a program that catches this should print it and leave with os._exit(non-zero) -- never exec -- so that torchrun / the bench's
+    supervisor starts fresh ranks (inference/versecrafter_inference.py does)."""
 
 
 class SequenceParallel:
@@ -495,6 +500,8 @@ class SequenceParallel:
         th.start()
         th.join(limit if limit > 0 else None)
         if th.is_alive():
+            global STALLED
+            STALLED = True
             raise SequenceParallelStall(
                 f"rank {self.rank}: ncclCommInitRank of the engine's communicators has not returned after {limit:.0f} s "
                 f"(world {self.world_size}).  The call cannot be cancelled: end this process and start fresh ranks with "

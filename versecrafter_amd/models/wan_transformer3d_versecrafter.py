@@ -668,6 +668,9 @@ class VerseCrafterWanTransformer3DModel(_ParamTree):
 
     def __del__(self):
         try:
+            from .. import dist as _vdist
+            if _vdist.STALLED:          # a helper thread is still inside ncclCommInitRank with this handle: leave it alone
+                return
             if getattr(self, "_engine", None) is not None and _lib._lib is not None:
                 _lib._lib.vc_destroy(self._engine)
                 self._engine = None
