@@ -692,6 +692,11 @@ def run_rank(args):
             if fp8_cls.get(dom):
                 kname = {"attn_self": "attn_fp8_kernel", "gemm": "gemm_pp_kernel<FP8>"}[dom]
                 traffic, traffic_src = None, None
+                try:
+                    if tj.get("workload") == args.workload and tj.get("n_gpus") == world and kname in tj:
+                        traffic, traffic_src = tj[kname]["bytes_per_launch"], tj.get("source")
+                except NameError:
+                    pass
             if any(fp8_cls.values()):
                 tot = sum(vv["flops"] for vv in prof.values()) or 1.0
                 f8 = sum(prof[c]["flops"] for c, on in fp8_cls.items() if on) / tot * f_step

@@ -107,10 +107,12 @@ def _up256(n):
     return (n + 255) // 256 * 256
 
 
+REC = 9216 + 10240      # one key-tile RECORD of the workspace: the K image of tile j followed by the V^T image of tile j - 1
+
+
 def workspace_bytes(B, H, Lq, Lk):
     nTq, nTk, bh = (Lq + KT - 1) // KT, (Lk + KT - 1) // KT, B * H
-    return (_up256(bh * nTq * KT * 128) + _up256(bh * nTq * KT * 4) + _up256(bh * nTk * 9216) + _up256(bh * nTk * 10240) +
-            2 * _up256(bh * nTk * 256))
+    return _up256(bh * nTq * KT * 128) + _up256(bh * nTq * KT * 4) + _up256(bh * (nTk + 3) * REC)
 
 
 def pack_workspace(Q):
@@ -128,19 +130,22 @@ def pack_workspace(Q):
     a = np.zeros((bh, nTq * KT, 4), np.uint8); m = np.zeros_like(a, bool)
     a[:, :Lq] = qs.reshape(bh, Lq, 4).numpy().astype(np.uint8); m[:, :Lq] = True
     ws[off:off + a.size] = a.ravel(); known[off:off + a.size] = m.ravel(); off += _up256(a.size)
-    # K8 [bh][tile][64 rows][144]: 128 data bytes + 16 zero bytes; rows past Lk are zero with scale byte 0 (amax 0)
+    # records [bh][nTk + 3][19456]: record j = K image of tile j (j < nTk) | V^T image of tile j - 1 (1 <= j <= nTk); the rest is never
+    # read by arithmetic (the attention kernel copies whole records, three past the last tile) and stays undefined
+    rec = np.zeros((bh, nTk + 3, REC), np.uint8); rm = np.zeros_like(rec, bool)
+    # K image: 64 rows (keys) at a pitch of 144: 128 data bytes, then 16 pad bytes of which the first four of row 32 b + r hold the scale
+    # bytes the MFMA lane 32 b + r supplies: byte kb * 2 + s  <-  key kb * 32 + r, block 2 s + b; rows past Lk are zero with scale byte 0
     kk = np.zeros((bh, nTk * KT, 128), np.uint8)
     kk[:, :Lk] = k8.reshape(bh, Lk, 128).numpy()
-    a = np.zeros((bh, nTk, KT, 144), np.uint8)
-    a[..., :128] = kk.reshape(bh, nTk, KT, 128)
-    ws[off:off + a.size] = a.ravel(); known[off:off + a.size] = True; off += _up256(a.size)
-    # Ks [bh][tile][256]: byte (b * 32 + r) * 4 + kb * 2 + s  <-  key kb * 32 + r, block 2 s + b
     kss = np.zeros((bh, nTk * KT, 4), np.uint8)
     kss[:, :Lk] = ks.reshape(bh, Lk, 4).numpy().astype(np.uint8)
     kss = kss.reshape(bh, nTk, 2, 32, 2, 2)                       # [bh][tile][kb][r][s][b]
-    a = kss.transpose(0, 1, 5, 3, 2, 4).copy()                    # [bh][tile][b][r][kb][s]
-    ws[off:off + a.size] = a.ravel(); known[off:off + a.size] = True; off += _up256(a.size)
-    # V8 [bh][tile][128 rows d][80]: byte 32 h + 16 kb + j  <-  key kb * 32 + (j & 3) + 8 (j >> 2) + 4 h
+    a = np.zeros((bh, nTk, KT, 144), np.uint8)
+    a[..., :128] = kk.reshape(bh, nTk, KT, 128)
+    a[..., 128:132] = kss.transpose(0, 1, 5, 3, 2, 4).reshape(bh, nTk, KT, 4)     # [bh][tile][b][r][kb][s] -> row 32 b + r
+    rec[:, :nTk, :9216] = a.reshape(bh, nTk, 9216); rm[:, :nTk, :9216] = True
+    # V^T image: 128 rows (d) at a pitch of 80: byte 32 h + 16 kb + j  <-  key kb * 32 + (j & 3) + 8 (j >> 2) + 4 h; pad bytes 64..67 of row
+    # 32 kb + r (rows 0..63) hold the scale bytes of lane 32 kb + r: byte db  <-  d = db * 32 + r, key block kb
     vv = v8.reshape(bh, nTk, KT, 128).numpy()
     a = np.zeros((bh, nTk, 128, 80), np.uint8)
     for hh in range(2):
@@ -148,11 +153,10 @@ def pack_workspace(Q):
             for j in range(16):
                 key = kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh
                 a[:, :, :, 32 * hh + 16 * kb + j] = vv[:, :, key, :]
-    ws[off:off + a.size] = a.ravel(); known[off:off + a.size] = True; off += _up256(a.size)
-    # Vs [bh][tile][256]: byte (kb * 32 + r) * 4 + db  <-  d = db * 32 + r, key block kb
     vss = vs.reshape(bh, nTk, 2, 4, 32).numpy().astype(np.uint8)    # [bh][tile][kb][db][r]
-    a = vss.transpose(0, 1, 2, 4, 3).copy()                          # [bh][tile][kb][r][db]
-    ws[off:off + a.size] = a.ravel(); known[off:off + a.size] = True; off += _up256(a.size)
+    a[:, :, :64, 64:68] = vss.transpose(0, 1, 2, 4, 3).reshape(bh, nTk, 64, 4)     # [bh][tile][kb][r][db] -> row 32 kb + r
+    rec[:, 1:nTk + 1, 9216:] = a.reshape(bh, nTk, 10240); rm[:, 1:nTk + 1, 9216:] = True
+    ws[off:off + rec.size] = rec.ravel(); known[off:off + rec.size] = rm.ravel()
     return ws, known
 
 

@@ -384,7 +384,9 @@ def test_ring_merge_of_eight_blocks_at_the_14b_head_shape_is_bounded(ops):
     torch.cuda.synchronize()
     e_ring, e_single, e_between = rel_l2(got, want), rel_l2(single, want), rel_l2(got, single.float().cpu())
     print(f"ring of 8 merged vs oracle {e_ring:.3g}; single pass vs oracle {e_single:.3g}; ring vs single pass {e_between:.3g}")
-    assert e_ring < 6e-3 and e_between < 2.5e-3
+    # measured (MI355X): 2.9e-3 / 2.4e-3 / 3.5e-3 -- eight bf16 partial outputs cost the merged result a fifth more error than the single
+    # pass has; the two results differ by about sqrt(2) x one bf16 rounding, as two independently rounded results do
+    assert e_ring < 4e-3 and e_ring < 1.5 * e_single and e_between < 5e-3
 
 
 # ----------------------------------------------------------------------------------------- row kernels

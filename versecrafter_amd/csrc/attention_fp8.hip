@@ -7,12 +7,16 @@
 //  1. attn_quant_fp8_kernel: one pass over the bf16 q / k / v of a (batch, head, 64-token tile) that writes
 //       Q8  [B][H][tile][64][128]  e4m3, natural d order, pre-multiplied by scale * log2(e) * 8 / 65535 (the softmax constant and the
 //                                  byte mapping of P below are folded into Q before it is quantised); Qs [..][64][4] scale bytes
-//       K8  [B][H][tile][9216]     the LDS IMAGE of the tile: 64 rows of 128 B at a pitch of 144 B (9 sixteen-byte slots: the 16 lanes of a
-//                                  ds_read_b128 group then fall on 16 different slots of the 256-byte bank row with NO xor swizzle, so a
-//                                  lane's two chunks stay adjacent and land in one 8-register tuple without moves); Ks [..][256]
-//       V8  [B][H][tile][10240]    V TRANSPOSED: 128 rows (d) of 64 B at a pitch of 80 B, the 64 keys of the tile in the order the P
-//                                  fragment holds them (below); Vs [..][256]
-//     so the attention kernel's LDS-DMA is a linear copy of whole images and no transposed LDS read is needed.
+//       KV  [B][H][nTk + 3][19456] one RECORD per key tile j = what the attention kernel copies into LDS in one beat, as it lies in LDS:
+//         bytes 0 .. 9215      the K image of tile j: 64 rows of 128 B at a pitch of 144 B (9 sixteen-byte slots: the 16 lanes of a
+//                              ds_read_b128 group then fall on 16 different slots of the 256-byte bank row with NO xor swizzle, so a
+//                              lane's two chunks stay adjacent and land in one 8-register tuple without moves); the first 4 of the 16 pad
+//                              bytes of row l hold the four block-scale bytes MFMA lane l supplies;
+//         bytes 9216 .. 19455  V of tile j - 1 TRANSPOSED (K runs one tile ahead of V in the kernel): 128 rows (d) of 64 B at a pitch of
+//                              80 B, the 64 keys of the tile in the order the P fragment holds them (below); pad bytes 0..3 of rows
+//                              0..63: the scale bytes of lane l.
+//       Record 0 has no V part, records nTk .. nTk+2 no K part (the copy runs three records ahead and is not clamped): never computed on.
+//     so the attention kernel's LDS-DMA is ONE linear copy per beat and no transposed LDS read is needed.
 //     Scale blocks follow the MFMA: the instruction's k-block b (32 of its 64 k) is bytes 16b .. 16b+15 of BOTH lane halves, and the
 //     scale of (row, block b) is supplied by lane 32 b + row (probed: tools/micro/fp8_attn_probe.hip).  A lane reads 32 contiguous bytes
 //     (2s+h)*32.. of its q / k row for k-step s, so block (s, b) of a q / k row is d in {64s+16b .. +15} u {64s+32+16b .. +15}; a block
@@ -20,8 +24,8 @@
 //     (no saturation: v_cvt_pk_fp8_f32 turns values >= 480 into NaN); elements are rounded to nearest even.
 //  2. attn_fp8_kernel: the structure of attn_fwd_pipe_kernel (8 waves x 32 query rows, 64-key tiles, S^T = K Q^T with the query on the
 //     lane, O^T += V^T P^T, software pipeline MFMA(S(t+1)) || VALU(P(t)), MFMA(PV(t)) || VALU(max(t+1)), deferred rescale) with
-//       * 4 + 4 MFMAs per tile instead of 16 + 16, half the LDS bytes, K / V / scales through a 4-deep LDS ring filled two tiles
-//         ahead by LDS-DMA behind a counted vmcnt(2) and a raw s_barrier;
+//       * 4 + 4 MFMAs per tile instead of 16 + 16, half the LDS bytes, whole records through a 4-deep LDS ring filled two tiles
+//         ahead by LDS-DMA (issued by waves 0-3 only: five instructions each, no branches) behind a counted vmcnt(5) and a raw s_barrier;
 //       * P per (row, tile) block-scaled: e = ceil(log2 of the tile's largest weight relative to the row's reference), P 2^(8-e) in
 //         e4m3 (largest byte in (112, 120]), the block scale 2^(e-8) goes into the MFMA's scale operand -- a tile far below the running
 //         maximum keeps full relative precision instead of flushing to zero;
@@ -40,15 +44,24 @@
 #include "vc_common.h"
 #include "vc_kernels.h"
 
+#ifdef F8_TRACE     // tools/trace_attn_fp8.py: per-wave sums of the core clock spent in each section of a beat
+__device__ uint64_t* vc_f8_trace_buf = nullptr;
+extern "C" int vc_debug_set_attn_fp8_trace(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(vc_f8_trace_buf), &buf, sizeof buf) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 constexpr int KT = 64;
 constexpr int KPITCH = 144, VPITCH = 80;          // row pitch of the K / V^T tile images (128 / 64 data bytes + 16 of padding)
-constexpr int KTILE = KT * KPITCH, VTILE = 128 * VPITCH, STILE = 256;      // bytes of a K image (9 KiB), a V^T image (10 KiB), a scale tile
-constexpr int NST = 4;                            // LDS ring depth
-constexpr int F8_KST = 0, F8_VST = NST * KTILE, F8_KSC = F8_VST + NST * VTILE, F8_VSC = F8_KSC + NST * STILE;
-constexpr int F8_ONES = F8_VSC + NST * STILE;     // 32 bytes of e4m3 1.0: the A operand of the row-sum MFMA, read like a fragment (broadcast)
-constexpr int F8_LDS = F8_ONES + 64;              // 78 KiB
+constexpr int KTILE = KT * KPITCH, VTILE = 128 * VPITCH;      // bytes of a K image (9 KiB) and of a V^T image (10 KiB)
+constexpr int REC = KTILE + VTILE;                // one record: K image of tile j | V^T image of tile j - 1 (19 KiB)
+constexpr int REC_PAD = 3;                        // records past the last tile that the kernel's copy may touch
+constexpr int NST = 4;                            // LDS ring depth (records)
+constexpr int F8_ONES = NST * REC;                // 32 bytes of e4m3 1.0: the A operand of the row-sum MFMA, read like a fragment (broadcast)
+constexpr int F8_LDS = F8_ONES + 64;              // 76 KiB
+constexpr int WPIECE = REC / 4;                   // bytes of a record one of the four copying waves moves: 4 x 1024 + 768
 typedef i32x8 __attribute__((aligned(16))) i32x8_a16;
 constexpr float K1 = 65535.0f / 8.0f;             // raw accumulator units -> log2 units
 constexpr float DEFER_T = 8.0f;                   // a row's reference follows its maximum once it is 2^8 behind (as the bf16 kernel)
@@ -89,6 +102,8 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, 
     const bf16_t* kp = (const bf16_t*)p.k + (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
     const bf16_t* vp = (const bf16_t*)p.v + (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
     char* ws = (char*)p.ws;
+    char* rec0 = ws + p.off_kv + (int64_t)bh * (nTk + REC_PAD) * REC;
+    __shared__ unsigned ksb[64], vsb[64];               // the scale dwords of the 64 MFMA lanes (bytes come from four threads each)
     const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;      // keys past it are quantised as zeros: they never reach a sum
     // ---- q and k rows: thread = (token r, block (s, bb)) ----
     {
@@ -141,11 +156,10 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, 
                 *(uint4*)(q8 + d1) = qhi;
                 (ws + p.off_qs + ((int64_t)bh * nTq + tile) * (KT * 4))[r * 4 + 2 * s + bb] = (char)sb;
             } else {
-                char* k8 = ws + p.off_k8 + ((int64_t)bh * nTk + tile) * KTILE + r * KPITCH;
+                char* k8 = rec0 + (int64_t)tile * REC + r * KPITCH;
                 *(uint4*)(k8 + d0) = qlo;
                 *(uint4*)(k8 + d1) = qhi;
-                if (blk == 0) *(uint4*)(k8 + 128) = uint4{0u, 0u, 0u, 0u};          // the pad travels with the image: keep it defined
-                (ws + p.off_ks + ((int64_t)bh * nTk + tile) * STILE)[(bb * 32 + (r & 31)) * 4 + (r >> 5) * 2 + s] = (char)sb;
+                ((char*)ksb)[(bb * 32 + (r & 31)) * 4 + (r >> 5) * 2 + s] = (char)sb;      // lane 32 bb + (r & 31): byte kb * 2 + s
             }
         }
     }
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, 
         }
         const int sb = mx_scale_byte(amax);
         const float inv = mx_inv_scale(sb);
-        char* v8 = ws + p.off_v8 + ((int64_t)bh * nTk + tile) * VTILE + d * VPITCH;
+        char* v8 = rec0 + (int64_t)(tile + 1) * REC + KTILE + d * VPITCH;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             float y[16];
@@ -170,8 +184,14 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, 
             for (int j = 0; j < 16; ++j) y[j] = x[(j & 3) + 8 * (j >> 2) + 4 * hh] * inv;     // the key order of the P fragment
             *(uint4*)(v8 + 32 * hh + 16 * kb) = cvt16_fp8(y);
         }
-        if (kb == 0) *(uint4*)(v8 + 64) = uint4{0u, 0u, 0u, 0u};
-        (ws + p.off_vs + ((int64_t)bh * nTk + tile) * STILE)[(kb * 32 + (d & 31)) * 4 + (d >> 5)] = (char)sb;
+        if (kb == 0 && d >= 64) *(uint4*)(v8 + 64) = uint4{0u, 0u, 0u, 0u};     // the pads travel with the image: keep them defined
+        ((char*)vsb)[(kb * 32 + (d & 31)) * 4 + (d >> 5)] = (char)sb;            // lane 32 kb + (d & 31): byte db
+    }
+    __syncthreads();
+    if (tile < nTk && tid < 128) {                       // the pad of image row l: lane l's scale dword, then zeros
+        const int l = tid & 63;
+        if (tid < 64) *(uint4*)(rec0 + (int64_t)tile * REC + l * KPITCH + 128) = uint4{ksb[l], 0u, 0u, 0u};
+        else *(uint4*)(rec0 + (int64_t)(tile + 1) * REC + KTILE + l * VPITCH + 64) = uint4{vsb[l], 0u, 0u, 0u};
     }
 }
 
@@ -213,6 +233,9 @@ VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_unifo
 #ifndef F8_ABLATE
 #define F8_ABLATE 0         // timing-only builds (WRONG results): 1 no DMA wait / barrier, 2 no LDS-DMA issue, 3 both, 4 no MFMA, 5 no conversion of P,
 #endif                      // 6 no fragment reads from LDS (tools/ablate_attn_fp8.sh)
+#ifndef F8_PRIO
+#define F8_PRIO 1           // s_setprio 1 around: 1 the QK^T phase, 2 the PV phase (A/B builds)
+#endif
 #ifndef F8_STAGGER
 #define F8_STAGGER 1        // waves 4-7 run the two phases of a beat in the other order (0: all eight waves in step)
 #endif
@@ -251,10 +274,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     const char* ws = (const char*)p.ws;
     const char* q8 = ws + p.off_q8 + (int64_t)bh * nTq * (KT * 128);
     const char* qs = ws + p.off_qs + (int64_t)bh * nTq * (KT * 4);
-    const char* k8 = ws + p.off_k8 + (int64_t)bh * nTk * KTILE;
-    const char* ks = ws + p.off_ks + (int64_t)bh * nTk * STILE;
-    const char* v8 = ws + p.off_v8 + (int64_t)bh * nTk * VTILE;
-    const char* vs = ws + p.off_vs + (int64_t)bh * nTk * STILE;
+    const char* rec0 = ws + p.off_kv + (int64_t)bh * (nTk + REC_PAD) * REC;
     bf16_t* op = (bf16_t*)p.out + (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
 
     const int k_len = (p.k_len > 0 && p.k_len < p.Lk) ? p.k_len : p.Lk;
@@ -263,51 +283,47 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
     const unsigned lane16 = (unsigned)(lane * 16);     // the wave's 1-KiB piece is selected through the scalar base
 
-    // One wave-instruction of LDS-DMA moves 1 KiB; a K image is 9 such pieces, a V^T image 10: wave w moves piece w of each, wave 0 also
-    // piece 8 of both, wave 1 piece 9 of V^T.  Loads of one loop iteration t (issued right after its barrier), in THIS order: the extras
-    // -- wave 0: K scales of tile t+2, piece 8 of K(t+3) and of V(t+2); wave 1: V scales of tile t+1, piece 9 of V(t+2) -- then EVERY
-    // wave's own piece of K(t+3) and of V(t+2).  At the top of the next iteration vmcnt(2) leaves only those last two in flight on every
-    // wave: scales have one iteration to land, tile images two.  Tiles past the last one are clamped (the slot they land in is free).
-    auto stage_k = [&](int tile, int slot, bool extras) {
-        const char* src = k8 + (int64_t)tile * KTILE;
-        const unsigned dst = lds0 + F8_KST + slot * KTILE;
-        if (extras) { if (wave == 0) f8_glds16(lane16, src + 8192, __builtin_amdgcn_readfirstlane(dst + 8192)); }
-        else f8_glds16(lane16, src + wave * 1024, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
+    // One wave-instruction of LDS-DMA moves 1 KiB; a record is 19 of them.  Waves 0-3 copy a quarter of the record each -- four whole
+    // instructions and one of 48 lanes under one M0 value, no branch -- and waves 4-7 none: the staggered half is the critical
+    // one (tools/trace_attn_fp8.py: with every wave issuing 2-5 pieces behind per-wave conditions the issue alone was 350-460 of a beat's
+    // 2530 clocks, and waves 0-3 then idled 500 at the barrier).  Beat t (right after its barrier) requests record t+3 = K(t+3) | V(t+2)
+    // into ring slot (t+3) & 3; at the top of the next beat vmcnt(5) leaves only that request in flight on the copying waves: a record has
+    // two beats to land.  The workspace holds three records past the last tile, so nothing is clamped.
+    // (the instruction offset of global_load_lds is added to the global AND to the LDS address: one M0 value serves the five pieces)
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * WPIECE + 1024u);
+    const char* src_w = rec0 + (int64_t)wave * WPIECE + 1024;          // + 1024: the five instruction offsets are -1024 .. 3072
+    auto copy_record = [&](int j) {
+        const char* src = src_w + (int64_t)j * REC;
+        const unsigned dst = lds_w + (unsigned)(j & 3) * REC;
+        unsigned keep;
+        uint64_t ex;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[v], %[src] offset:-1024\n\t"
+            "global_load_lds_dwordx4 %[v], %[src]\n\t"
+            "global_load_lds_dwordx4 %[v], %[src] offset:1024\n\t"
+            "global_load_lds_dwordx4 %[v], %[src] offset:2048\n\t"
+            "s_mov_b64 %[ex], exec\n\ts_mov_b32 exec_hi, 0xffff\n\t"            // lanes 0-47 (exec is all ones here: wave-uniform code)
+            "global_load_lds_dwordx4 %[v], %[src] offset:3072\n\t"
+            "s_mov_b64 exec, %[ex]\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep), [ex] "=&s"(ex)
+            : [dst] "s"(dst), [v] "v"(lane16), [src] "s"(src)
+            : "memory", "scc");
     };
-    auto stage_v = [&](int tile, int slot, bool extras) {
-        const char* src = v8 + (int64_t)tile * VTILE;
-        const unsigned dst = lds0 + F8_VST + slot * VTILE;
-        if (extras) { if (wave < 2) f8_glds16(lane16, src + 8192 + wave * 1024, __builtin_amdgcn_readfirstlane(dst + 8192 + wave * 1024)); }
-        else f8_glds16(lane16, src + wave * 1024, __builtin_amdgcn_readfirstlane(dst + wave * 1024));
-    };
-    // lane * 4 is derived from lane * 16 where it is needed, by an instruction hipcc cannot hoist out of the tile loop: as a loop invariant
-    // it (and the LDS addresses built on it) ended up spilled, and a spill reload inside the loop waits vmcnt(0) -- draining the LDS-DMA ring
-    auto lane4_now = [&]() { unsigned a; asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(a) : "v"(lane16)); return a; };
-    auto stage_ks = [&](int tile, int slot) {
-        if (wave == 0) f8_glds4(lane4_now(), ks + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_KSC + slot * STILE));
-    };
-    auto stage_vs = [&](int tile, int slot) {
-        if (wave == 1) f8_glds4(lane4_now(), vs + (int64_t)tile * STILE, __builtin_amdgcn_readfirstlane(lds0 + F8_VSC + slot * STILE));
-    };
-    auto issue = [&](int t) {
-        const int tks = min(t + 2, nt - 1), tvs = min(t + 1, nt - 1), tk = min(t + 3, nt - 1), tv = min(t + 2, nt - 1);
-        stage_ks(tks, (t + 2) & 3);
-        stage_vs(tvs, (t + 1) & 3);
-        stage_k(tk, (t + 3) & 3, true);
-        stage_v(tv, (t + 2) & 3, true);
-        stage_k(tk, (t + 3) & 3, false);
-        stage_v(tv, (t + 2) & 3, false);
-    };
-    // ---- prologue loads: K(0), K(1), V(0) and the scales of K(0), K(1), V(0), drained once; then what "iteration -1" would have issued ----
-    {
-        const int t1 = min(1, nt - 1), t2 = min(2, nt - 1);
-        stage_ks(0, 0); stage_ks(t1, 1); stage_vs(0, 0);
-        stage_k(0, 0, true); stage_k(0, 0, false);
-        stage_k(t1, 1, true); stage_k(t1, 1, false);
-        stage_v(0, 0, true); stage_v(0, 0, false);
+    // lane * 4 ... are derived from lane * 16 where they are needed, by an instruction hipcc cannot hoist out of the tile loop: as loop
+    // invariants they (and the LDS addresses built on them) ended up spilled, and a spill reload inside the loop waits vmcnt(0) -- draining
+    // the LDS-DMA ring
+    auto ksc_off = [&]() { unsigned a; asm volatile("v_mul_u32_u24 %0, 9, %1" : "=v"(a) : "v"(lane16)); return a + 128u; };   // lane * 144 + 128
+    auto vsc_off = [&]() { unsigned a; asm volatile("v_mul_u32_u24 %0, 5, %1" : "=v"(a) : "v"(lane16)); return a + 64u + (unsigned)KTILE; };
+    auto issue = [&](int t) { if (wave < 4) copy_record(t + 3); };
+    // ---- prologue loads: records 0 and 1 (K(0), K(1), V(0)), drained once; then what "beat -1" would have requested ----
+    if (wave < 4) {
+        copy_record(0);
+        copy_record(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stage_k(t2, 2, true); stage_v(t1, 1, true);
-        stage_k(t2, 2, false); stage_v(t1, 1, false);
+        copy_record(2);
     }
 
     // ---- Q fragments and scales (registers for the whole kernel) ----
@@ -336,8 +352,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     float m_run = -1e30f, m_new = -1e30f, m_tile = -1e30f;       // raw accumulator units (x K1 = log2 units)
 
     auto qk = [&](int t, f32x16 (&S)[2]) {                        // S(t) = K(t) Q^T : 4 MFMAs
-        const char* kbuf = smem + F8_KST + (t & 3) * KTILE;
-        const int ksc = *(const int*)(smem + F8_KSC + (t & 3) * STILE + lane4_now());
+        const char* kbuf = smem + (t & 3) * REC;
+        const int ksc = *(const int*)(kbuf + ksc_off());
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             i32x8 kf[2];
@@ -396,20 +412,50 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     // tile, then phase 1 of this one -- so that on every SIMD one wave is in its VALU-heavy QK^T phase (and its serial head: barrier, DMA
     // issue, rescale test) while its partner feeds the matrix pipe from the VALU-light PV phase (MI355X_MICROARCH.md "Two waves per SIMD",
     // item 9; same per-row operation order, so both halves give bit-identical rows).
-    // Fragment reads sit one MFMA gap ahead of the MFMA that takes them.  (Reading a whole phase ahead -- all K fragments behind the beat's
-    // barrier, the V^T fragments in the QK^T gaps, 243 VGPRs -- was measured and is SLOWER: 23.2 ms against 21.1 ms at the bench shape,
-    // profiles/r04_attn_fp8_ablate.txt; the LDS round trip is not what the waves wait for.)
-    i32x8 pf;
-    int pscale = 0;
+    // Fragment reads sit one or two MFMA gaps ahead of the MFMA that takes them; the reads of a phase's FIRST MFMA are issued before the
+    // phase: K(t+1)'s first half right behind the beat's barrier (in front of the DMA issue and the rescale arithmetic, or -- staggered half
+    // -- of the whole phase 2), V(t)'s first fragment and scales in the last gap of phase 1.  (Reading a WHOLE phase ahead -- all K
+    // fragments behind the barrier, all V^T fragments in the QK^T gaps, 243 VGPRs -- was measured and is slower: 23.2 ms against 21.1 ms
+    // at the bench shape, profiles/r04_attn_fp8_ablate.txt.)
+    i32x8 pf, k00, k01, vf0, vf1;
+    int pscale = 0, ksc = 0, vsc = 0;
+    const i32x8 ones = *(const i32x8_a16*)(smem + F8_ONES);        // every lane the same 32 bytes (written before the prologue's barrier)
+    const int unit = *(const int*)(smem + F8_ONES + 32);
 #define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef F8_TRACE
+    uint64_t trc_acc[5] = {0, 0, 0, 0, 0}, trc_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_last) :: "memory");
+    const uint64_t trc_t0 = trc_last;
+    auto mark = [&](int i) {
+        uint64_t now;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        trc_acc[i] += now - trc_last;
+        trc_last = now;
+    };
+#define F8_MARK(i) mark(i)
+#else
+#define F8_MARK(i) do {} while (0)
+#endif
     auto beat_head = [&](int t) {
         F8_FENCE();
+        F8_MARK(4);
         if (F8_ABLATE != 1 && F8_ABLATE != 3) {
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // all but the two youngest pieces: K(t+1), V(t), their scales are in LDS
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // (copying waves) all but the youngest record: record t+1 = K(t+1) | V(t) is in LDS
             __builtin_amdgcn_s_barrier();                         // ... for every wave; and every wave is past its reads of the slots refilled now
         }
         F8_FENCE();
+        F8_MARK(0);
+        if (t + 1 < nt) {
+            const char* kbuf = smem + ((t + 1) & 3) * REC;
+            ksc = *(const int*)(kbuf + ksc_off());
+            k00 = *(const i32x8_a16*)(kbuf + koff);
+            k01 = *(const i32x8_a16*)(kbuf + koff + 64);
+        }
+        F8_FENCE();
         if (F8_ABLATE != 2 && F8_ABLATE != 3) issue(t);
+        F8_MARK(1);
     };
     auto phase1 = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
         const bool MORE = t + 1 < nt;
@@ -460,10 +506,9 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
             pf[kb * 4 + i0 + 1] = w1;
         };
         if (MORE) {
-            const char* kbuf = smem + F8_KST + ((t + 1) & 3) * KTILE;
-            const int ksc = *(const int*)(smem + F8_KSC + ((t + 1) & 3) * STILE + lane4_now());
-            const i32x8 k00 = *(const i32x8_a16*)(kbuf + koff), k01 = *(const i32x8_a16*)(kbuf + koff + 64);
+            const char* kbuf = smem + ((t + 1) & 3) * REC;
             F8_FENCE();
+            if (F8_PRIO == 1) __builtin_amdgcn_s_setprio(1);
             F8_MFMA_ZERO(Sn[0], k00, qf[0], ksc, qsc, F8_OPS_00);
             const i32x8 k10 = *(const i32x8_a16*)(kbuf + 32 * KPITCH + koff);
             pgap(0, 0);
@@ -473,12 +518,19 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
             pgap(0, 2);
             F8_FENCE();
             F8_MFMA_ZERO(Sn[1], k10, qf[0], ksc, qsc, F8_OPS_20);
+            vsc = *(const int*)(smem + ((t + 1) & 3) * REC + vsc_off());          // V(t) travels in record t + 1
+            vf0 = *(const i32x8_a16*)(smem + ((t + 1) & 3) * REC + KTILE + voff);
             pgap(1, 0);
             F8_FENCE();
             F8_MFMA(Sn[1], k11, qf[1], ksc, qsc, F8_OPS_32);
+            vf1 = *(const i32x8_a16*)(smem + ((t + 1) & 3) * REC + KTILE + 32 * VPITCH + voff);
             pgap(1, 2);
+            if (F8_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             F8_FENCE();
         } else {
+            vsc = *(const int*)(smem + ((t + 1) & 3) * REC + vsc_off());
+            vf0 = *(const i32x8_a16*)(smem + ((t + 1) & 3) * REC + KTILE + voff);
+            vf1 = *(const i32x8_a16*)(smem + ((t + 1) & 3) * REC + KTILE + 32 * VPITCH + voff);
             pgap(0, 0); pgap(0, 2); pgap(1, 0); pgap(1, 2);
             F8_FENCE();
         }
@@ -486,35 +538,31 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     auto phase2 = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
         const bool MORE = t + 1 < nt;
         const bool MASK = MORE && tail_partial && (t + 2 == nt);
-        const char* vbuf = smem + F8_VST + (t & 3) * VTILE;
+        const char* vbuf = smem + ((t + 1) & 3) * REC + KTILE;     // V(t) travels in record t + 1
         i32x8 vf[4];
-        const int vsc = *(const int*)(smem + F8_VSC + (t & 3) * STILE + lane4_now());
-        vf[0] = *(const i32x8_a16*)(vbuf + voff);
+        vf[0] = vf0;
+        vf[1] = vf1;
+        vf[2] = *(const i32x8_a16*)(vbuf + 64 * VPITCH + voff);
         // PV gaps: a quarter of S(t+1)'s row maximum each, unconditionally (no branch, no copies at merge points: on the last tile and on the
         // masked one -- which takes its maximum again behind the mask -- the result is simply not used)
         float mxa = -1e30f;
         // the tile's row sum FIRST, into the registers of S(t) (dead: P(t) has been packed): 1^T P^T has 32 equal rows, element 0 is
         // added to the running sum once the four MFMAs behind it have been issued
-        {
-            const i32x8 ones = *(const i32x8_a16*)(smem + F8_ONES);            // every lane the same 32 bytes: a broadcast read, no register kept
-            const int unit = *(const int*)(smem + F8_ONES + 32);
-            F8_FENCE();
-            F8_MFMA_ZERO_NOP(Sc[0], ones, pf, unit, pscale, F8_OPS_00);
-        }
-        vf[1] = *(const i32x8_a16*)(vbuf + 32 * VPITCH + voff);
+        F8_FENCE();
+        if (F8_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        F8_MFMA_ZERO_NOP(Sc[0], ones, pf, unit, pscale, F8_OPS_00);
+        vf[3] = *(const i32x8_a16*)(vbuf + 96 * VPITCH + voff);
         asm volatile("" : "+v"(Sn[0]));                           // written at least two MFMAs before the one just issued
 #pragma unroll
         for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, Sn[0][e]);
         asm volatile("" : "+v"(mxa));
         F8_FENCE();
         F8_MFMA(O[0], vf[0], pf, vsc, pscale, F8_OPS_00);
-        vf[2] = *(const i32x8_a16*)(vbuf + 64 * VPITCH + voff);
 #pragma unroll
         for (int e = 8; e < 16; ++e) mxa = fmaxf(mxa, Sn[0][e]);
         asm volatile("" : "+v"(mxa));
         F8_FENCE();
         F8_MFMA(O[1], vf[1], pf, vsc, pscale, F8_OPS_10);
-        vf[3] = *(const i32x8_a16*)(vbuf + 96 * VPITCH + voff);
         asm volatile("" : "+v"(Sn[1]));                           // at least three MFMAs behind the last QK^T one
 #pragma unroll
         for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, Sn[1][e]);
@@ -526,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
         asm volatile("" : "+v"(mxa));
         F8_FENCE();
         F8_MFMA(O[3], vf[3], pf, vsc, pscale, F8_OPS_30);
+        if (F8_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         F8_FENCE();
         asm volatile("" : "+v"(Sc[0]));
         l_run += Sc[0][0];
@@ -546,20 +595,30 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     const bool stag = F8_STAGGER != 0 && wave >= 4;
     for (int t = 0; t <= nt; t += 2) {
         if (t < nt) beat_head(t);
-        if (stag && t > 0) phase2(t - 1, Sb, Sa);
+        if (stag && t > 0) { phase2(t - 1, Sb, Sa); F8_MARK(3); }
         if (t < nt) {
             phase1(t, Sa, Sb);
-            if (!stag) phase2(t, Sa, Sb);
+            F8_MARK(2);
+            if (!stag) { phase2(t, Sa, Sb); F8_MARK(3); }
         }
         if (t + 1 <= nt) {
             if (t + 1 < nt) beat_head(t + 1);
-            if (stag && t < nt) phase2(t, Sa, Sb);
+            if (stag && t < nt) { phase2(t, Sa, Sb); F8_MARK(3); }
             if (t + 1 < nt) {
                 phase1(t + 1, Sb, Sa);
-                if (!stag) phase2(t + 1, Sb, Sa);
+                F8_MARK(2);
+                if (!stag) { phase2(t + 1, Sb, Sa); F8_MARK(3); }
             }
         }
     }
+#ifdef F8_TRACE
+    if (vc_f8_trace_buf && lane == 0) {
+        uint64_t* o = vc_f8_trace_buf + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = trc_acc[i];
+        o[5] = trc_last - trc_t0;
+        o[6] = (uint64_t)nt;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may still be landing in LDS when the workgroup retires
     F8_MFMA_SETTLE4(O[0], O[1], O[2], O[3]);
 
@@ -605,7 +664,7 @@ inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
 int64_t vc_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
     const int64_t nTq = (Lq + KT - 1) / KT, nTk = (Lk + KT - 1) / KT, bh = (int64_t)B * H;
-    return up256(bh * nTq * KT * 128) + up256(bh * nTq * KT * 4) + up256(bh * nTk * KTILE) + up256(bh * nTk * VTILE) + 2 * up256(bh * nTk * STILE);
+    return up256(bh * nTq * KT * 128) + up256(bh * nTq * KT * 4) + up256(bh * (nTk + REC_PAD) * REC);
 }
 
 static int fp8_attn_fill(VcAttnFp8Params& p, int64_t ws_bytes) {
@@ -618,10 +677,7 @@ static int fp8_attn_fill(VcAttnFp8Params& p, int64_t ws_bytes) {
     int64_t off = 0;
     p.off_q8 = off; off += up256(bh * nTq * KT * 128);
     p.off_qs = off; off += up256(bh * nTq * KT * 4);
-    p.off_k8 = off; off += up256(bh * nTk * KTILE);
-    p.off_ks = off; off += up256(bh * nTk * STILE);
-    p.off_v8 = off; off += up256(bh * nTk * VTILE);
-    p.off_vs = off;
+    p.off_kv = off;
     p.qfold = (float)((double)p.scale * 1.4426950408889634 * 8.0 / 65535.0);
     return VC_OK;
 }

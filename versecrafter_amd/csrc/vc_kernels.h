@@ -103,7 +103,7 @@ struct VcAttnFp8Params {
     int pmode;
     void* ws;
     // filled by the launcher
-    int64_t off_q8, off_qs, off_k8, off_ks, off_v8, off_vs;
+    int64_t off_q8, off_qs, off_kv;
     float qfold;
 };
 int64_t vc_attention_fp8_workspace_bytes(int B, int H, int Lq, int Lk);
