@@ -47,6 +47,9 @@ namespace {
 #ifndef VC_ATTN_DEFAULT_SHAPE
 #define VC_ATTN_DEFAULT_SHAPE 32    // 32: v_mfma_f32_32x32x16_bf16 (this file); 16: v_mfma_f32_16x16x32_bf16 (attention16.hip)
 #endif
+#ifndef VC_ATTN_FOLD
+#define VC_ATTN_FOLD 0      // round 4: the softmax constant folded into Q (once per workgroup) and the row's exponent reference into the C
+#endif                      // operand of the first QK^T MFMA of a tile: P = exp2(S) with no v_fma_f32 per element (A/B: tools/ab_attn.sh)
 #ifndef VC_ATTN_QK_INTERLEAVE
 #define VC_ATTN_QK_INTERLEAVE 0
 #endif
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         const int from = p.pad_from[b];
         if (from >= 0 && from < p.Lk - 1) {
             k_len = from + 1;
-            pad_bias = log2f((float)(p.Lk - from)) / (p.scale * 1.4426950408889634f);
+            pad_bias = VC_ATTN_FOLD ? log2f((float)(p.Lk - from)) : log2f((float)(p.Lk - from)) / (p.scale * 1.4426950408889634f);
         }
     }
     const int nt = (k_len + KT - 1) / KT;
@@ -213,6 +216,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         const bf16_t* qrow = qp + tok_off<SEG>(q_row_c, p.q_ts, p.seg_len, p.q_ss) + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 16);
+#if VC_ATTN_FOLD
+        // Q' = bf16(q * scale * log2 e): the accumulator of K Q'^T is the logit in log2 units (one more bf16 rounding of q, 2^-9 relative:
+        // 1e-3 of a log2 unit on a logit, a tenth of the rounding P itself gets)
+        const float cq = p.scale * 1.4426950408889634f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)((float)qf[ks][j] * cq);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
@@ -233,8 +245,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[i][e] = 0.f;
-    const float c = p.scale * 1.4426950408889634f;
+    const float c = VC_ATTN_FOLD ? 1.0f : p.scale * 1.4426950408889634f;     // FOLD: S, m_run, m_new are in log2 units already
     float m_run = -1e30f, m_new = -1e30f, l_run = 0.f;
+#if VC_ATTN_FOLD
+    // sixteen copies of -m_run: the C operand of the first MFMA of every 32-key half, so that S arrives as (logit - reference) and
+    // the weights are exp2(S) without a multiply-add per element.  Invariant at the top of body(t): Sc = S(t) - m_run.  The reference
+    // moves rarely (deferred rescale): the branch that moves it also shifts the S(t) at hand and rewrites the sixteen copies.
+    f32x16 bias;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias[e] = 0.f;
+#endif
 
     auto qk = [&](const char* kbuf, f32x16 (&S)[2]) {
 #if VC_ATTN_QK_INTERLEAVE      // the two 32-key halves alternate: every MFMA depends on the one TWO back, not on its predecessor
@@ -270,6 +290,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
                 S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], S[kb], 0, 0, 0);
+            }
+        }
+#elif VC_ATTN_FOLD
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kbuf + lc.koff[ks] + kb * 8192);
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? bias : S[kb], 0, 0, 0);
             }
         }
 #else
@@ -313,6 +342,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     qk(smem + P_KST, Sa);
     if (nt == 1) mask_tail(Sa, 0);
     m_new = fmaxf(m_new, row_max(Sa));
+#if VC_ATTN_FOLD
+    m_run = m_new;                      // O and l are still zero: the first reference is simply taken
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Sa[kb][e] -= m_run;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bias[e] = -m_run;
+    asm volatile("" : "+v"(bias));      // opaque: or hipcc rebuilds the sixteen copies in front of every MFMA that takes them
+#endif
 
     // one pipelined iteration; PAR = t & 1 (static LDS stages); MORE: tile t+1 exists (compute S(t+1) into Sn);
     // MASK: tile t+1 is the last one.  Sc = S(t) on entry; the caller swaps the roles of the two buffers.
@@ -338,10 +377,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) O[i][e] *= alpha;
+#if VC_ATTN_FOLD
+                const float shift = m_run - m_ref;               // S(t) was accumulated on top of -m_run
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Sc[kb][e] += shift;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bias[e] = -m_ref;
+                asm volatile("" : "+v"(bias));
+#endif
                 m_run = m_ref;
             }
         }
-        const float mc = m_run * c;
+        [[maybe_unused]] const float mc = m_run * c;
         // ---- phase 1: MFMA S(t+1) = K(t+1).Q^T  ||  VALU P(t) = exp2(S(t) c - m c), row sums, bf16 pack ----
         if (MORE) qk(smem + P_KST + (PAR ^ 1) * TILE_BYTES, Sn);
         // row sums.  hipcc sinks this 32-add chain behind the next barrier; VC_ATTN_ROWSUM = n > 0 builds n independent partial
@@ -377,6 +426,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             for (int j = 0; j < 8; ++j) {
 #if VC_ATTN_ABLATE == 1        // timing ablation only (wrong results): the transcendental replaced by a plain VALU op
                 const float pe = Sc[s >> 1][8 * (s & 1) + j] * c - mc;
+#elif VC_ATTN_FOLD
+                const float pe = __builtin_amdgcn_exp2f(Sc[s >> 1][8 * (s & 1) + j]);
 #else
                 const float pe = __builtin_amdgcn_exp2f(Sc[s >> 1][8 * (s & 1) + j] * c - mc);
 #endif
@@ -409,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             }
         if (MORE) {
             if (MASK) mask_tail(Sn, t + 1);
-            m_new = fmaxf(m_new, row_max(Sn));       // true running maximum (>= m_run)
+            m_new = fmaxf(m_new, row_max(Sn) + (VC_ATTN_FOLD ? m_run : 0.f));       // true running maximum (>= m_run)
         }
     };
     using T_ = std::true_type;
