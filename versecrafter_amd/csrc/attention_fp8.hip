@@ -233,6 +233,9 @@ VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_unifo
 #ifndef F8_ABLATE
 #define F8_ABLATE 0         // timing-only builds (WRONG results): 1 no DMA wait / barrier, 2 no LDS-DMA issue, 3 both, 4 no MFMA, 5 no conversion of P,
 #endif                      // 6 no fragment reads from LDS (tools/ablate_attn_fp8.sh)
+#ifndef F8_ASM_GAPS
+#define F8_ASM_GAPS 0       // pmode 1: a gap's fourteen conversion instructions as ONE asm statement (0: C++ with an opaque copy of the constant per gap)
+#endif
 #ifndef F8_PRIO
 #define F8_PRIO 1           // s_setprio 1 around: 1 the QK^T phase, 2 the PV phase (A/B builds)
 #endif
@@ -498,6 +501,26 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
         };
         auto pgap = [&](int kb, int i0) {                         // dwords i0, i0 + 1 of half kb
             if (F8_ABLATE == 5) { pf[kb * 4 + i0] = __float_as_int(Sc[kb][4 * i0]); pf[kb * 4 + i0 + 1] = __float_as_int(Sc[kb][4 * i0 + 4]); return; }
+            if (PMODE == 1 && F8_ASM_GAPS) {
+                // the same fourteen instructions as one asm statement: ordered against the MFMA statements by being volatile, and no
+                // per-gap copy of the constant (the opaque-copy form below costs a v_mov and an s_nop per gap)
+                int w0, w1;
+                float t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile(
+                    "v_add_f32 %[t0], %[s0], %[k]\n\tv_add_f32 %[t1], %[s1], %[k]\n\tv_add_f32 %[t2], %[s2], %[k]\n\tv_add_f32 %[t3], %[s3], %[k]\n\t"
+                    "v_add_f32 %[t4], %[s4], %[k]\n\tv_add_f32 %[t5], %[s5], %[k]\n\tv_add_f32 %[t6], %[s6], %[k]\n\tv_add_f32 %[t7], %[s7], %[k]\n\t"
+                    "v_cvt_pknorm_u16_f32 %[t0], %[t0], %[t1]\n\tv_cvt_pknorm_u16_f32 %[t2], %[t2], %[t3]\n\t"
+                    "v_cvt_pknorm_u16_f32 %[t4], %[t4], %[t5]\n\tv_cvt_pknorm_u16_f32 %[t6], %[t6], %[t7]\n\t"
+                    "v_perm_b32 %[w0], %[t2], %[t0], %[sel]\n\tv_perm_b32 %[w1], %[t6], %[t4], %[sel]"
+                    : [w0] "=&v"(w0), [w1] "=&v"(w1), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),
+                      [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+                    : [s0] "v"(Sc[kb][4 * i0]), [s1] "v"(Sc[kb][4 * i0 + 1]), [s2] "v"(Sc[kb][4 * i0 + 2]), [s3] "v"(Sc[kb][4 * i0 + 3]),
+                      [s4] "v"(Sc[kb][4 * i0 + 4]), [s5] "v"(Sc[kb][4 * i0 + 5]), [s6] "v"(Sc[kb][4 * i0 + 6]), [s7] "v"(Sc[kb][4 * i0 + 7]),
+                      [k] "v"(kc), [sel] "s"(0x06040200));
+                pf[kb * 4 + i0] = w0;
+                pf[kb * 4 + i0 + 1] = w1;
+                return;
+            }
             float k = kc;
             asm volatile("" : "+v"(k));
             const int w0 = pconv(kb, i0, k), w1 = pconv(kb, i0 + 1, k);
