@@ -3,7 +3,7 @@
 #   1. attn_fp8_kernel at the cfg-3 shape: issue / wait / MFMA / LDS / L2 counters
 #   2. gemm_pp_kernel under the two tile maps (tile 4 production, tile 6 shared super-band) at 5120^2 and 5120->13824: FETCH_SIZE, L2 hits, clock
 set -e
-tag=${1:-r04}
+tag=${1:-r04}      # tools/pmc_round4.sh TAG [attn-only]
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -18,6 +18,7 @@ for p in A B C D; do
   rocprofv3 --pmc $cs --output-format csv -d $out/${tag}_pmc_af8_$p -o run -- python3 $root/tools/prof_attn_fp8.py 1 > /dev/null 2> $out/${tag}_pmc_af8_$p.err
 done
 echo "attention passes done" >&2
+[ "$2" = "attn-only" ] && { cd $root; python3 tools/summarize_pmc_round4.py $out $tag > $out/${tag}_pmc_round4.txt || true; cat $out/${tag}_pmc_round4.txt; exit 0; }
 for t in 4 6; do
   for shape in "5120 5120" "13824 5120"; do
     n=${shape% *}

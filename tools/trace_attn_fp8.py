@@ -23,6 +23,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 assert lib.vc_debug_set_attn_fp8_trace(buf.data_ptr()) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(int(os.environ.get('WARM', '0'))):       # the guide's clock check: stamp after >= 2 s of back-to-back launches
+    ops.attention_fp8(q, k, v, out=out, workspace=ws, stage=2, pmode=1)
 e0.record()
 ops.attention_fp8(q, k, v, out=out, workspace=ws, stage=2, pmode=1)
 e1.record()
@@ -32,6 +34,10 @@ t = buf.cpu().double().view(nwg, 8, 8)
 t = t[t[:, 0, 6] > 0]
 nt = t[:, :, 6]
 print(f"traced launch {e0.elapsed_time(e1):.2f} ms; {t.shape[0]} workgroups, {int(nt[0, 0])} key tiles each")
+clk = (t[:, :, 5] / t[:, :, 7].clamp(min=1)) * 100e6
+print(f"in-kernel clock (s_memtime / s_memrealtime around the loop, median over waves): {clk.median().item() / 1e9:.3f} GHz "
+      f"(10th / 90th percentile {clk.flatten().kthvalue(max(1, int(0.1 * clk.numel()))).values.item() / 1e9:.3f} / "
+      f"{clk.flatten().kthvalue(int(0.9 * clk.numel())).values.item() / 1e9:.3f})")
 names = ["wait+barrier", "DMA issue", "phase 1", "phase 2", "loop control"]
 for grp, sl in (("waves 0-3 (phase 1, phase 2)", slice(0, 4)), ("waves 4-7 (phase 2 of t-1, phase 1 of t)", slice(4, 8)), ("wave 0", slice(0, 1)), ("wave 1", slice(1, 2)), ("wave 2", slice(2, 3))):
     per = (t[:, sl, :5] / nt[:, sl, None]).mean(dim=(0, 1))

@@ -30,6 +30,13 @@
 #include "vc_common.h"
 #include "vc_kernels.h"
 
+#ifdef VC_ATTN_CLOCK   // tools/clock_attn.py: s_memtime / s_memrealtime around the tile loop of attn_fwd_pipe_kernel (diagnostic build only)
+__device__ uint64_t* vc_attn_clock_buf = nullptr;
+extern "C" int vc_debug_set_attn_clock(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(vc_attn_clock_buf), &buf, sizeof buf) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 
 #ifndef VC_ATTN_DEFER_MAX
@@ -467,6 +474,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     using F_ = std::false_type;
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+#ifdef VC_ATTN_CLOCK
+    uint64_t clk_c0, clk_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0) :: "memory");
+#endif
     // tiles 0 .. nt-3 in pairs (S(t) alternates between Sa and Sb), then the masked and the final tile
     int t = 0;
     for (; t + 3 < nt; t += 2) {
@@ -485,6 +496,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         body(t, Sa, Sb, P0{}, F_{}, F_{});
     }
 
+#ifdef VC_ATTN_CLOCK
+    {
+        uint64_t clk_c1, clk_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c1), "=s"(clk_r1) :: "memory");
+        if (vc_attn_clock_buf && lane == 0) {
+            uint64_t* o = vc_attn_clock_buf + ((size_t)blockIdx.x * NW + wave) * 2;
+            o[0] = clk_c1 - clk_c0;
+            o[1] = clk_r1 - clk_r0;
+        }
+    }
+#endif
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     // Epilogue (round 4: the widened store tail of attn_short_kernel, cdna_hip_programming.md T21): a lane holds 8-byte pieces (4 dims)

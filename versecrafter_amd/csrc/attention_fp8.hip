@@ -429,6 +429,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     uint64_t trc_acc[5] = {0, 0, 0, 0, 0}, trc_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_last) :: "memory");
     const uint64_t trc_t0 = trc_last;
+    uint64_t trc_r0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_r0) :: "memory");        // 100 MHz: the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz
     auto mark = [&](int i) {
         uint64_t now;
         __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +439,11 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
         trc_acc[i] += now - trc_last;
         trc_last = now;
     };
+#ifdef F8_CLOCK_ONLY       // stamps around the whole loop only: the clock the UNPERTURBED loop holds
+#define F8_MARK(i) do {} while (0)
+#else
 #define F8_MARK(i) mark(i)
+#endif
 #else
 #define F8_MARK(i) do {} while (0)
 #endif
@@ -638,8 +644,13 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     if (vc_f8_trace_buf && lane == 0) {
         uint64_t* o = vc_f8_trace_buf + ((size_t)blockIdx.x * 8 + wave) * 8;
         for (int i = 0; i < 5; ++i) o[i] = trc_acc[i];
-        o[5] = trc_last - trc_t0;
+        uint64_t trc_c1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_c1) :: "memory");
+        o[5] = trc_c1 - trc_t0;
         o[6] = (uint64_t)nt;
+        uint64_t trc_r1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_r1) :: "memory");
+        o[7] = trc_r1 - trc_r0;
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing may still be landing in LDS when the workgroup retires
