@@ -4,7 +4,8 @@
      json, the file set of the reference's demo_data folders) -> the five control videos (.mp4, the package's own I_PCM writer)
   2. inference/versecrafter_inference.py     -- Wan2.1-14B + GeoAdapter (random weights), production-width Wan VAE (random weights),
      random prompt embeddings, N denoise steps, VAE decode -> generated_video_0.mp4
-   python tools/e2e_fullsize.py [workdir] [steps] [H] [W] [moe]      moe: a second 14B expert runs the high-noise steps (BASELINE config 5's pair)"""
+   python tools/e2e_fullsize.py [workdir] [steps] [H] [W] [moe] [fp8]      moe: a second 14B expert runs the high-noise steps (BASELINE config 5's
+   pair); fp8: --fp8_linear 1 --fp8_attention 1 (config 5's dtype)"""
 import json
 import os
 import subprocess
@@ -24,7 +25,8 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 480
     W = int(sys.argv[4]) if len(sys.argv) > 4 else 832
-    moe = len(sys.argv) > 5 and sys.argv[5] == "moe"
+    moe = "moe" in sys.argv[5:]
+    fp8 = "fp8" in sys.argv[5:]
     F_ = 81
     os.makedirs(work, exist_ok=True)
     rs = np.random.RandomState(0)
@@ -77,8 +79,9 @@ def main():
                         "--num_inference_steps", str(steps), "--sample_size", f"{H},{W}", "--video_length", str(F_), "--save_path", out_dir,
                         "--synthetic_model", "14b", "--vae_path", os.path.join(work, "vae.safetensors"), "--prompt_embeds_path",
                         os.path.join(work, "embeds.safetensors"), "--output_latents", "1"] +
-                       (["--synthetic_high_noise_expert", "--shift", "12"] if moe else []), capture_output=True, text=True)
-    print(f"[2] inference CLI: rc {r.returncode}, {time.time() - t0:.1f} s wall ({'two 14B experts' if moe else '14B'} random init + 4 VAE encodes + {steps} steps + decode)")
+                       (["--synthetic_high_noise_expert", "--shift", "12"] if moe else []) +
+                       (["--fp8_linear", "1", "--fp8_attention", "1"] if fp8 else []), capture_output=True, text=True)
+    print(f"[2] inference CLI: rc {r.returncode}, {time.time() - t0:.1f} s wall ({'two 14B experts' if moe else '14B'}{', fp8 linear layers + fp8 self-attention' if fp8 else ''} random init + 4 VAE encodes + {steps} steps + decode)")
     print("    " + "\n    ".join((r.stdout.strip().splitlines() or [""])[-3:]))
     if r.returncode:
         raise SystemExit(r.stderr[-3000:])
