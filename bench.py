@@ -244,7 +244,8 @@ def launch_ranks(args):
     (a torchrun worker) -- it owns the child of its own rank and agrees with the other supervisors through the store.
 
     Per attempt: children must mark "started" (VC_BENCH_START_TIMEOUT, default 300 s: a cold `import torch` takes minutes)
-    and then "up" (VC_BENCH_UP_TIMEOUT, default 90 s after the last "started": communicators created, probe exchange done);
+    and then "up" (VC_BENCH_UP_TIMEOUT, default 90 s after the last "started" -- 150 s on the first attempt of an N >= 4 run, which
+    brings three layouts' communicators up: communicators created, probe exchange done);
     the whole run has VC_BENCH_BUDGET seconds (default 560: below the driver's limit).  A stall, or a rank that dies between
     "started" and "up", is a transport failure: attempt 2 runs fresh children with VC_SP_TRANSPORT=torch.  Any other failure,
     or a failed attempt 2, ends the run non-zero with every rank's stderr tail."""
@@ -256,6 +257,9 @@ def launch_ranks(args):
     budget = float(os.environ.get("VC_BENCH_BUDGET", "560"))
     t_start_lim = float(os.environ.get("VC_BENCH_START_TIMEOUT", "300"))
     t_up_lim = float(os.environ.get("VC_BENCH_UP_TIMEOUT", "90"))
+    # the first attempt of an N >= 4 run brings the communicators of three layouts up (and probes each): 30 s more per extra layout
+    n_layouts0 = 3 if (n >= 4 and n % 2 == 0 and not args.single_layout and not args.cfg_degree and args.ring_degree <= 1) else 1
+    t_up_extra0 = 30.0 * (n_layouts0 - 1) if "VC_BENCH_UP_TIMEOUT" not in os.environ else 0.0
     grace = float(os.environ.get("VC_BENCH_KILL_GRACE", "10"))
     log_dir = os.environ.get("VC_BENCH_LOG_DIR") or os.getcwd()
     child_cmd = os.environ.get("VC_BENCH_TEST_CHILD")              # tests: a stand-in rank program
@@ -338,9 +342,9 @@ def launch_ranks(args):
                     break
                 elif n_started < n and now - t_spawn > t_start_lim:
                     board.set(f"fail{a}", f"stall: {n_started} of {n} ranks started within {t_start_lim:.0f} s")
-                elif n_started >= n and n_up < n and now - t_all_started > t_up_lim:
-                    board.set(f"fail{a}", f"stall: {n_up} of {n} ranks brought their communicators up within {t_up_lim:.0f} s "
-                                          f"of starting")
+                elif n_started >= n and n_up < n and now - t_all_started > t_up_lim + (t_up_extra0 if a == 0 else 0.0):
+                    board.set(f"fail{a}", f"stall: {n_up} of {n} ranks brought their communicators up within "
+                                          f"{t_up_lim + (t_up_extra0 if a == 0 else 0.0):.0f} s of starting")
                 elif now - t_begin > budget:
                     board.set(f"fail{a}", f"stall: over the run budget of {budget:.0f} s")
                 time.sleep(0.1)
