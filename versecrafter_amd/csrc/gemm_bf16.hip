@@ -583,9 +583,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
         }
     }
     const float* wscale = FP8 ? (grp == 0 ? p.w_scale : p.w_scaleg[grp - 1]) + nb : nullptr;   // fp8: output-channel scales of this lane's columns
+    // fp8: the sixteen channel scales of this lane's columns and (per pass, below) the token scales of its rows are read BEFORE the first
+    // store, like everything else the epilogue reads: a load issued behind a store can only be waited for together with that store (the
+    // vmcnt queue is in order), and with the scales re-read row by row that was eight store round trips in a row -- the K sweep read
+    // 14.3 us per output tile for the fp8 kernel against 9-12 for the bf16 one (profiles/r04_gemm_fp8_ksweep.txt)
+    f32x4 wsv[4];
+    if constexpr (FP8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wsv[j] = *(const f32x4*)(wscale + j * 16);
+    }
     uint2 rr[HINT ? 16 : 32], hh[16];      // residual fragments of a pass (32 without a hint, 16 + 16 hint fragments with one)
     auto pass = [&](auto i0_c, auto i1_c) __attribute__((always_inline)) {
         constexpr int I0 = decltype(i0_c)::value, I1 = decltype(i1_c)::value;
+        float ascv[I1 - I0];
+        if constexpr (FP8) {
+#pragma unroll
+            for (int i = I0; i < I1; ++i) {
+                const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+                ascv[i - I0] = p.a_scale[m < p.M ? m : p.M - 1];
+            }
+            if (!NEED_R) __builtin_amdgcn_sched_barrier(0);
+        }
         if (NEED_R) {
 #pragma unroll
             for (int i = I0; i < I1; ++i) {
@@ -623,7 +641,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
             const unsigned keep = dead ? 0u : 0xFFFFFFFFu;            // rows past valid_rows are written as +0.0
             bf16_t* crow = C + (int64_t)m * p.ldc + nst;
             float asc = 1.f;
-            if constexpr (FP8) asc = p.a_scale[m];
+            if constexpr (FP8) asc = ascv[i - I0];
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
                 uint2 pk[2];
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(VcGemmParams p, int nTm, i
                     const int j = jp * 2 + jj;
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if constexpr (FP8) {
-                        const f32x4 wsj = *(const f32x4*)(wscale + j * 16);     // re-read per row: 16 more registers would spill
+                        const f32x4 wsj = wsv[j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= asc * wsj[e];
                     }
