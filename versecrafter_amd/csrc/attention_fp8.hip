@@ -231,8 +231,8 @@ VC_DEVICE void f8_glds4(unsigned voff, const void* sbase, unsigned lds_dst_unifo
 #define F8_POST ""
 #endif
 #ifndef F8_ABLATE
-#define F8_ABLATE 0         // timing-only builds (WRONG results): 1 no DMA wait / barrier, 2 no LDS-DMA issue, 3 both, 4 no MFMA, 5 no conversion of P,
-#endif                      // 6 no fragment reads from LDS (tools/ablate_attn_fp8.sh)
+#define F8_ABLATE 0         // timing-only builds (WRONG results): 1 no DMA wait / barrier, 2 no LDS-DMA issue, 3 both, 4 no MFMA, 5 no conversion of P
+#endif                      // (tools/build_variant.sh + tools/time_attn_fp8_core.py; what they can and cannot show: profiles/r04_attn_fp8_ablate.txt)
 #ifndef F8_ASM_GAPS
 #define F8_ASM_GAPS 0       // pmode 1: a gap's fourteen conversion instructions as ONE asm statement (0: C++ with an opaque copy of the constant per gap)
 #endif
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(VcAttnFp8Params p, int
     // ---- prologue: S(0) and its row maximum ----
     f32x16 Sa[2], Sb[2];
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                 // every wave's pieces of K(0), K(1), V(0) and their scales landed before its vmcnt(0) above
+    __builtin_amdgcn_s_barrier();                                 // the copying waves' pieces of records 0, 1 (K(0), K(1), V(0)) landed before their vmcnt(0) above
     __builtin_amdgcn_sched_barrier(0);
     qk(0, Sa);
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(Sa[0]), "+v"(Sa[1]));
