@@ -550,7 +550,7 @@ def _deq(q, sc):
     return q.view(torch.float8_e4m3fn).float() * sc[:, None]
 
 
-@pytest.mark.parametrize("M,K", [(5, 256), (300, 512), (1024, 5120), (77, 13824)])
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 512), (1024, 5120), (77, 13824), (33, 20480)])     # 1, 1, 3, 7 register trips; two-pass form
 def test_fp8_row_quantiser_equals_torch_cast(ops, M, K):
     """vc_op_quantize_rows_fp8: scale = amax / 448 per row, bytes = torch's own round-to-nearest-even cast to OCP e4m3 of x / scale."""
     g = torch.Generator().manual_seed(M + K)

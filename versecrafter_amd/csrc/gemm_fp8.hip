@@ -13,21 +13,36 @@
 
 namespace {
 
-// one 256-thread workgroup per row; 16 bytes (8 bf16) per thread and trip
+// one 256-thread workgroup per row; 16 bytes (8 bf16) per thread and trip.  The row stays in registers between the amax pass and the
+// conversion (NCH trips of 16 bytes per thread: K <= 2048 NCH), so it is read once and every load is issued before the first store (a
+// load behind a store is waited for together with the store: in-order vmcnt).  K > 16384 takes the two-pass form (NCH = 0).
+template <int NCH>
 __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
                                                                 float* __restrict__ scale, int M, int K) {
     __shared__ float red[4];
+    const int nch = K / 8;
     for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
         const bf16_t* row = x + m * ldx;
         float amax = 0.f;
-        for (int c = threadIdx.x; c < K / 8; c += 256) {
-            const uint4 v = *(const uint4*)(row + c * 8);
+        uint4 keep[NCH > 0 ? NCH : 1];
+        auto amax8 = [&](const uint4& v) {
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 amax = fmaxf(amax, fabsf(__uint_as_float(w[e] << 16)));
                 amax = fmaxf(amax, fabsf(__uint_as_float(w[e] & 0xFFFF0000u)));
             }
+        };
+        if (NCH > 0) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = threadIdx.x + i * 256;
+                keep[i] = c < nch ? *(const uint4*)(row + c * 8) : uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) amax8(keep[i]);
+        } else {
+            for (int c = threadIdx.x; c < nch; c += 256) amax8(*(const uint4*)(row + c * 8));
         }
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_down(amax, o));
         __syncthreads();                                   // red[] of the previous row has been read
@@ -38,8 +53,7 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
         const float inv = 1.0f / sc;
         if (threadIdx.x == 0) scale[m] = sc;
         uint8_t* qrow = q + m * ldq;
-        for (int c = threadIdx.x; c < K / 8; c += 256) {
-            const uint4 v = *(const uint4*)(row + c * 8);
+        auto cvt8 = [&](const uint4& v, int c) {
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
             unsigned out[2];
 #pragma unroll
@@ -50,6 +64,15 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
                 else out[e >> 1] = (unsigned)pk & 0xFFFFu;
             }
             *(uint2*)(qrow + c * 8) = uint2{out[0], out[1]};
+        };
+        if (NCH > 0) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = threadIdx.x + i * 256;
+                if (c < nch) cvt8(keep[i], c);
+            }
+        } else {
+            for (int c = threadIdx.x; c < nch; c += 256) cvt8(*(const uint4*)(row + c * 8), c);
         }
     }
 }
@@ -60,7 +83,13 @@ int vc_launch_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq
     if (!x || !q || !scale || M <= 0 || K <= 0) return VC_E_INVALID;
     if (K % 8 || ldx % 8 || ldq % 8 || ((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return VC_E_UNSUPPORTED;
     const int grid = M < (1 << 20) ? M : (1 << 20);
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, M, K);
+    const int trips = (K / 8 + 255) / 256;
+#define VC_QROWS(N) hipLaunchKernelGGL(quantize_rows_fp8_kernel<N>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, M, K)
+    if (trips <= 1) VC_QROWS(1);
+    else if (trips <= 3) VC_QROWS(3);          // d = 5120: 640 chunks
+    else if (trips <= 8) VC_QROWS(8);          // ffn 13824: 1728 chunks
+    else VC_QROWS(0);
+#undef VC_QROWS
     return hipGetLastError() == hipSuccess ? VC_OK : VC_E_HIP;
 }
 
