@@ -199,6 +199,65 @@ def test_sp_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, monkeypatch)
         assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
 
 
+@pytest.mark.parametrize("P,seq_len,cfg_pair,lanes,linear", [(2, 72, False, None, False), (4, 75, True, None, True), (2, 75, True, "2", True),
+                                                            (4, 72, False, "3", False), (2, 75, False, "1", True)])
+def test_sp_with_fp8_modes_equals_single_rank_bitwise(P, seq_len, cfg_pair, lanes, linear, monkeypatch):
+    """BASELINE config 5 as it is worded is "SP = 8, fp8 MFMA": the fp8 self-attention (and, `linear`, the fp8 linear layers) under the
+    Ulysses exchange.  Every quantisation block is local to a (token, head) or to a (32-key block, channel) and every row scale to a
+    token, so splitting heads and tokens over ranks changes no byte: each rank's output equals the single-rank fp8 engine's bit for bit.
+    lanes "2": sample lanes slice the lane's fp8 workspace per sample."""
+    if lanes is not None:
+        monkeypatch.setenv("VC_DUAL_LANE", lanes)
+    cfg = O.Config(**TINY)
+    W = O.random_weights(cfg, 11)
+    g = torch.Generator().manual_seed(1)
+    T, h, w = 3, 8, 12
+    x = torch.randn(2, 16, T, h, w, generator=g).bfloat16().cuda()
+    geo = torch.randn(2, 128, T, h, w, generator=g).bfloat16().cuda()
+    if cfg_pair:
+        x[1], geo[1] = x[0], geo[0]
+    ctx = [torch.randn(20, 64, generator=g).bfloat16().cuda(), torch.randn(33, 64, generator=g).bfloat16().cuda()]
+    t = torch.tensor([640.0, 640.0]).cuda()
+
+    def fp8(m):
+        m.enable_fp8_attention(True, 1)
+        if linear:
+            m.enable_fp8_linear()
+        return m
+
+    padded = (seq_len + P - 1) // P * P
+    bf16_ref = make_model(W)(x, t, geo, ctx, padded)
+    ref = fp8(make_model(W))(x, t, geo, ctx, padded)
+    torch.cuda.synchronize()
+    assert not torch.equal(ref, bf16_ref)                       # the mode is really on
+    comm = FakeComm(P)
+    models, sps = [], []
+    for r in range(P):
+        m = fp8(make_model(W))
+        sp = FakeSP(comm, r)
+        m.enable_multi_gpus_inference(sp)
+        models.append(m)
+        sps.append(sp)
+    outs, errs = [None] * P, [None] * P
+
+    def run(r):
+        try:
+            outs[r] = models[r](x, t, geo, ctx, seq_len)
+        except Exception as e:
+            errs[r] = e
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert errs[r] is None, (r, errs[r], sps[r].error)
+        assert torch.equal(outs[r], ref), f"rank {r}: max diff {(outs[r].float() - ref.float()).abs().max()}"
+
+
 @pytest.mark.parametrize("P,ring,seq_len,cfg_pair,lanes", [
     (4, 2, 72, False, None), (2, 2, 72, False, None), (4, 2, 75, True, None), (4, 4, 72, False, "0"), (4, 2, 72, True, "2"),
     (4, 2, 75, True, "3"), (2, 2, 75, False, "1"), (4, 2, 44, False, None), (4, 2, 576, True, None), (4, 2, 510, False, "2"),
