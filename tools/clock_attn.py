@@ -15,7 +15,7 @@ qkv = torch.randn(B, L, 3 * d, device="cuda", generator=g).bfloat16()
 q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (H, 128)) for i in range(3))
 out = torch.empty(B, L, H, 128, device="cuda", dtype=torch.bfloat16)
 nwg = (B * H * ((L + 255) // 256) + 7) // 8 * 8
-buf = torch.zeros(nwg * 8, 2, dtype=torch.int64, device="cuda")
+buf = torch.zeros(nwg * 8, 8, dtype=torch.int64, device="cuda")
 ops.attention(q, k, v, out=out)
 torch.cuda.synchronize()
 assert lib.vc_debug_set_attn_clock(buf.data_ptr()) == 0
@@ -36,3 +36,9 @@ ghz = clk.median().item() / 1e9
 print(f"attn_fwd_pipe_kernel B=2 H=40 L=32760 after {os.environ.get('WARM', '60')} warm launches: {ms:.2f} ms = {tf:.0f} TFLOP/s; in-kernel clock {ghz:.3f} GHz "
       f"(10th / 90th percentile {clk.kthvalue(max(1, int(0.1 * clk.numel()))).values.item() / 1e9:.3f} / {clk.kthvalue(int(0.9 * clk.numel())).values.item() / 1e9:.3f}); "
       f"dense bf16 peak at that clock {2500 * ghz / 2.4:.0f} TFLOP/s -> fraction {tf / (2500 * ghz / 2.4):.3f}")
+if t[:, 7].max() > 0:            # a -DVC_ATTN_TRACE build: s_memtime sums per section (the fences perturb hipcc's schedule: indicative only)
+    nt = t[:, 7].clamp(min=1)
+    per = (t[:, 2:7] / nt[:, None]).mean(0).tolist()
+    tot = (t[:, 0] / nt).mean().item()
+    names = ["wait + barrier", "K / V staging (4 LDS-DMA pieces)", "rescale test + phase 1", "phase 2 + row maximum", "loop control"]
+    print(f"per tile and wave: {tot:.0f} clocks = " + ", ".join(f"{n} {x:.0f} ({100 * x / tot:.0f} %)" for n, x in zip(names, per)))

@@ -360,15 +360,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
     asm volatile("" : "+v"(bias));      // opaque: or hipcc rebuilds the sixteen copies in front of every MFMA that takes them
 #endif
 
+#ifdef VC_ATTN_TRACE     // (with VC_ATTN_CLOCK) s_memtime sums per section of a tile: the fences change hipcc's schedule -- indicative only
+    uint64_t trc_acc[5] = {0, 0, 0, 0, 0}, trc_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trc_last) :: "memory");
+    auto trc_mark = [&](int i) {
+        uint64_t now;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        trc_acc[i] += now - trc_last;
+        trc_last = now;
+    };
+#define VC_ATTN_MARK(i) trc_mark(i)
+#else
+#define VC_ATTN_MARK(i) do {} while (0)
+#endif
     // one pipelined iteration; PAR = t & 1 (static LDS stages); MORE: tile t+1 exists (compute S(t+1) into Sn);
     // MASK: tile t+1 is the last one.  Sc = S(t) on entry; the caller swaps the roles of the two buffers.
     auto body = [&](int t, f32x16 (&Sc)[2], f32x16 (&Sn)[2], auto par_tag, auto more_tag, auto mask_tag) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool MORE = decltype(more_tag)::value, MASK = decltype(mask_tag)::value;
+        VC_ATTN_MARK(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // K(t+1), V(t) landed; all waves are past QK(t) [Kst[PAR]] and PV(t-1) [Vst[PAR^1]]
+        VC_ATTN_MARK(0);
         if (t + 2 < nt) stage(t + 2, true, false, PAR, 0);
         if (MORE) stage(t + 1, false, true, 0, PAR ^ 1);
+        VC_ATTN_MARK(1);
         // Deferred rescale (VC_ATTN_DEFER_MAX = T > 0): a row's exponent reference m_run follows its true running maximum
         // m_new only once the row has outgrown it by more than 2^T; until then P = exp2((S - m_run) c) may exceed 1
         // (< 2^T: harmless in bf16 / fp32).  O and l carry the same factor, so the quotient is unchanged; only the
@@ -449,6 +467,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         }
 #endif
         if (VC_ATTN_ROWSUM > 0) asm volatile("" : "+v"(l_run));
+        VC_ATTN_MARK(2);
         // ---- phase 2: MFMA O += V(t)^T.P(t)^T  ||  VALU row maxima of S(t+1) ----
         const char* vbuf = smem + P_VST + PAR * TILE_BYTES;
 #pragma unroll
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
             if (MASK) mask_tail(Sn, t + 1);
             m_new = fmaxf(m_new, row_max(Sn) + (VC_ATTN_FOLD ? m_run : 0.f));       // true running maximum (>= m_run)
         }
+        VC_ATTN_MARK(3);
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -501,9 +521,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         uint64_t clk_c1, clk_r1;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c1), "=s"(clk_r1) :: "memory");
         if (vc_attn_clock_buf && lane == 0) {
-            uint64_t* o = vc_attn_clock_buf + ((size_t)blockIdx.x * NW + wave) * 2;
+            uint64_t* o = vc_attn_clock_buf + ((size_t)blockIdx.x * NW + wave) * 8;
             o[0] = clk_c1 - clk_c0;
             o[1] = clk_r1 - clk_r0;
+#ifdef VC_ATTN_TRACE
+            for (int i = 0; i < 5; ++i) o[2 + i] = trc_acc[i];
+            o[7] = (uint64_t)nt;
+#endif
         }
     }
 #endif
