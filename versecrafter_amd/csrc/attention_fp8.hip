@@ -168,11 +168,29 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(VcAttnFp8Params p, 
         const int d = tid & 127, kb = tid >> 7;
         float x[32];
         float amax = 0.f;
+        // the tile of V goes through LDS: 16 bytes per lane from global memory (a key row's 128 channels are contiguous), columns read back
+        // per thread; rows whose strides or base are not 16-byte aligned take the 2-byte loads directly
+        __shared__ __attribute__((aligned(16))) unsigned short vt[KT][136];
+        const bool wide_v = ((p.v_ts | p.v_hs | p.v_bs) & 7) == 0 && ((uintptr_t)p.v & 15) == 0;
+        if (wide_v) {
+            const int kr = tid >> 2, qd = tid & 3, key = tile * KT + kr;
+            const bf16_t* src = vp + (int64_t)key * p.v_ts + qd * 32;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int key = tile * KT + kb * 32 + i;
-            x[i] = key < k_len ? (float)vp[(int64_t)key * p.v_ts + d] : 0.f;
-            amax = fmaxf(amax, fabsf(x[i]));
+            for (int i = 0; i < 4; ++i)
+                *(uint4*)&vt[kr][qd * 32 + 8 * i] = key < k_len ? *(const uint4*)(src + 8 * i) : uint4{0u, 0u, 0u, 0u};
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                x[i] = __uint_as_float((unsigned)vt[kb * 32 + i][d] << 16);
+                amax = fmaxf(amax, fabsf(x[i]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int key = tile * KT + kb * 32 + i;
+                x[i] = key < k_len ? (float)vp[(int64_t)key * p.v_ts + d] : 0.f;
+                amax = fmaxf(amax, fabsf(x[i]));
+            }
         }
         const int sb = mx_scale_byte(amax);
         const float inv = mx_inv_scale(sb);
