@@ -381,7 +381,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(VcAttnParams 
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool MORE = decltype(more_tag)::value, MASK = decltype(mask_tag)::value;
         VC_ATTN_MARK(4);
+#if VC_ATTN_ABLATE != 5    // 5: timing ablation only (a data race): what the wait for the tiles requested ONE beat earlier costs = what a deeper ring could win
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();   // K(t+1), V(t) landed; all waves are past QK(t) [Kst[PAR]] and PV(t-1) [Vst[PAR^1]]
         VC_ATTN_MARK(0);
         if (t + 2 < nt) stage(t + 2, true, false, PAR, 0);
